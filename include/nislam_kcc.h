@@ -1,0 +1,148 @@
+/*
+ * nislam_kcc.h -- C ABI of libnislam_kcc_hip.so: the MI355X (gfx950) implementation of
+ * NI-SLAM's Kernel-Cross-Correlator front end.
+ *
+ * The reference has no FFI: its de-facto boundary is the public interface of class
+ * CorrelationFlow (reference include/correlation_flow.h:8-33), called from
+ * MapBuilder (src/map_builder.cc:23,72-75,127-131) and LoopClosure (src/loop_closure.cc:55-59).
+ * Each entry point below names the reference interface it replaces.  The header-only C++
+ * adaptor ni-slam_amd/correlation_flow_hip.h re-creates that class on top of this ABI.
+ *
+ * Conventions
+ *   - plain C types only; all functions return NIK_OK (0) or a negative nik_status; nothing
+ *     throws across the ABI.  nik_last_error() returns a human-readable message.
+ *   - host arrays use the reference's layouts:
+ *       image     : Eigen::ArrayXXf  column-major H x W           -> a[c*H + r], values in [0,1]
+ *       spectrum  : Eigen::ArrayXXcf column-major (H/2+1) x W     -> s[c*(H/2+1) + k], (re,im) floats
+ *       polar sp. : Eigen::ArrayXXcf column-major (PD/2+1) x PC
+ *       u8 image  : cv::Mat CV_8UC1 row-major H x W               -> m[r*stride + c]
+ *   - "dev" entry points take DEVICE pointers (HBM-resident inputs) and are stream-ordered.
+ *   - a nik_frame is a slot in the context's device-resident keyframe store (the analogue of
+ *     reference Frame's _fft_result/_fft_polar members, include/frame.h:32-39).
+ */
+#ifndef NISLAM_KCC_H
+#define NISLAM_KCC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    NIK_OK = 0,
+    NIK_ERR_INVALID_ARG = -1,
+    NIK_ERR_UNSUPPORTED_SIZE = -2,   /* FFT length not instantiated / odd dimension */
+    NIK_ERR_INVALID_KERNEL = -3,     /* reference: throw std::invalid_argument("Received invalid kernel type"), correlation_flow.cc:167-168 */
+    NIK_ERR_HIP = -4,                /* a HIP runtime call failed (no device, OOM, launch failure) */
+    NIK_ERR_CAPACITY = -5,           /* batch larger than max_batch / frame slot out of range */
+    NIK_ERR_NOT_READY = -6           /* frame slot holds no spectra yet */
+} nik_status;
+
+/* mirrors CFConfig, reference include/read_configs.h:15-25 (same field order and types) */
+typedef struct {
+    int   width;
+    int   height;
+    float lambda;
+    int   kernel;             /* 0 polynomial, 1 gaussian; anything else -> NIK_ERR_INVALID_KERNEL at pose time */
+    float sigma;
+    float offset;
+    int   power;
+    int   rotation_divisor;   /* polar rows (angle bins) */
+    int   rotation_channel;   /* polar cols (radius bins) */
+} nik_config;
+
+typedef struct nik_ctx nik_ctx;
+typedef int32_t nik_frame;    /* slot index in [0, max_frames) */
+
+/* raw per-pair results of ComputePose (reference correlation_flow.cc:97-143) */
+typedef struct {
+    double pose[3];           /* (x px, y px, theta rad)  == reference `pose` out-param            */
+    double info[3];           /* (PSR_t, PSR_t, PSR_r)    == reference return value                 */
+    int32_t rot_row, rot_col; /* arg-max of the rotation surface (column-major first max)           */
+    int32_t trans_row[2], trans_col[2];   /* arg-max of the translation surface, hypothesis 0 / 1   */
+    float   psr_rot, psr_trans[2];
+    float   degree_final;     /* degrees, after the >180 fold of :134                               */
+    int32_t chosen;           /* 0 = `orig`, 1 = `veri` (+180) hypothesis (:121-131)                */
+    int32_t n_hyp;            /* 1 (not_large_rotation) or 2                                        */
+} nik_pose_result;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+
+/* replaces CorrelationFlow::CorrelationFlow(CFConfig&, double& H, double& W) (correlation_flow.cc:37-44).
+ * As in the reference, cfg->height/width are overridden by image_height/image_width.
+ * max_batch  : largest number of frame pairs (or loop-closure candidates) per batched call.
+ * max_frames : capacity of the device keyframe store.
+ * device     : HIP device ordinal. */
+int  nik_create(const nik_config* cfg, int image_height, int image_width,
+                int max_batch, int max_frames, int device, nik_ctx** out);
+void nik_destroy(nik_ctx* ctx);
+const char* nik_last_error(const nik_ctx* ctx);      /* ctx may be NULL: last create() error */
+/* geometry queries (H, W, PD, PC, max_batch, max_frames) */
+int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
+/* stream the context launches on (a hipStream_t, returned as void*) */
+void* nik_stream(const nik_ctx* ctx);
+int  nik_synchronize(nik_ctx* ctx);
+
+/* ---- ComputeIntermedium (correlation_flow.cc:89-95) ------------------------------------- */
+
+/* replaces MapBuilder::ComputeFFTResult (map_builder.cc:72-75): ConvertMatToNormalizedArray
+ * (utils.cc:110-118) + ComputeIntermedium.  `gray` is a host CV_8UC1 image, row stride in bytes. */
+int nik_intermedium_u8(nik_ctx* ctx, const uint8_t* gray, int stride, nik_frame dst);
+/* replaces CorrelationFlow::ComputeIntermedium(const ArrayXXf&, ArrayXXcf&, ArrayXXcf&): host f32 image,
+ * column-major H x W.  Results stay on the device in slot `dst`; fetch them with nik_frame_export. */
+int nik_intermedium_f32(nik_ctx* ctx, const float* image_colmajor, nik_frame dst);
+/* batched, device-resident inputs: n u8 images [n][H][W] (row-major, tightly packed) already in HBM. */
+int nik_intermedium_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_frame* dst);
+
+/* copy a slot's contents to host arrays in the reference layouts (any pointer may be NULL):
+ * the image (reference Frame::_frame), fft_result, fft_polar. */
+int nik_frame_export(nik_ctx* ctx, nik_frame f, float* image_colmajor,
+                     float* fft_result /*2*(H/2+1)*W floats*/, float* fft_polar /*2*(PD/2+1)*PC floats*/);
+/* load host arrays (reference layouts) into a slot -- lets spectra computed elsewhere (e.g. by the
+ * reference itself) be used as keys: the ComputePose(const ArrayXXcf& last_fft_result, ...) arguments. */
+int nik_frame_import(nik_ctx* ctx, nik_frame f, const float* image_colmajor,
+                     const float* fft_result, const float* fft_polar);
+
+/* ---- ComputePose (correlation_flow.cc:97-143) -------------------------------------------- */
+
+/* replaces CorrelationFlow::ComputePose(last_fft_result, image, last_fft_polar, fft_polar, pose,
+ * not_large_rotation) for one pair: `key` supplies last_fft_result/last_fft_polar, `cur` supplies
+ * image/fft_polar.  pose/info as the reference.  res (optional) receives the raw arg-max indices. */
+int nik_pose(nik_ctx* ctx, nik_frame key, nik_frame cur, int not_large_rotation,
+             double pose[3], double info[3], nik_pose_result* res);
+/* n independent pairs (MapBuilder::Tracking over a batch, map_builder.cc:127-131). */
+int nik_pose_batch(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
+                   int not_large_rotation, nik_pose_result* res);
+
+/* The benchmark unit of SURVEY.md 8(d): for each of n pairs,
+ *   ComputeIntermedium(current image) + ComputePose(key, current, not_large_rotation).
+ * d_gray: n u8 images in HBM; keys[i]: slot holding pair i's keyframe spectra; cur_dst[i]: slot that
+ * receives the current frame's image + spectra (so it can become a key later, map_builder.cc:99-106).
+ * Asynchronous on nik_stream(); results land in `res` (host) after nik_synchronize(), or call with
+ * sync=1 to block.  res may be pageable host memory. */
+int nik_track_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_frame* keys,
+                        const nik_frame* cur_dst, int not_large_rotation, nik_pose_result* res, int sync);
+
+/* replaces the per-candidate loop of LoopClosure::FindLoopClosure (loop_closure.cc:40-66): runs
+ * ComputePose(cand_i, query, not_large_rotation=false) for n candidates and returns every result
+ * plus the index of the candidate with the largest response.sum() (first such in `cands` order),
+ * or -1 when n == 0.  The frame-gap / distance filters (:43-53) stay with the caller. */
+int nik_match(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands,
+              int* best, nik_pose_result* res /* n entries, may be NULL */, nik_pose_result* best_res);
+
+/* ---- debug / parity taps (used by tests only) --------------------------------------------- */
+
+/* CorrelationFlow::FFT / IFFT (correlation_flow.cc:53-77) on host arrays in the reference layouts.
+ * which: 0 = image geometry (H x W), 1 = polar geometry (PD x PC). */
+int nik_dbg_fft (nik_ctx* ctx, int which, const float* x_colmajor, float* xf_out);
+int nik_dbg_ifft(nik_ctx* ctx, int which, const float* xf, float* x_out);
+/* RotateArray (utils.cc:154-161) of slot f's image by `degree2`/2 degrees (degree2 = 2*degree, integer). */
+int nik_dbg_rotate(nik_ctx* ctx, nik_frame f, int degree2, float* out_colmajor);
+/* polar(fftshift(RemoveZeroComponent(x))) (correlation_flow.cc:93-94) of a host H x W plane. */
+int nik_dbg_polar(nik_ctx* ctx, const float* x_colmajor, float* out_colmajor /*PD x PC*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

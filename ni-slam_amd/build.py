@@ -1,0 +1,43 @@
+"""Build libnislam_kcc_hip.so in-tree with hipcc for gfx950 (explicit hipcc -shared -fPIC; no JIT cache)."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libnislam_kcc_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+UNITS = [("kcc_kernels.hip", []), ("kcc_api.hip", ["-ffp-contract=off"])]
+HEADERS = ["kcc_fft.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    for src, extra in UNITS:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + hdrs):
+            cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    if force or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

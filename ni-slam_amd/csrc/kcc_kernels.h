@@ -1,0 +1,117 @@
+// kcc_kernels.h -- host-visible launch interface of the HIP kernels (internal to libnislam_kcc_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kcc {
+
+// raw reduction output of one response surface (arg-max + moments), per item
+struct SurfaceResult {
+    double sum, sumsq;
+    float  peak;
+    int    idx;          // linear column-major index  (col * rows + row)
+};
+
+// per-block partial of the same
+struct Partial {
+    double sum, sumsq;
+    float  peak;
+    int    idx;
+};
+
+// kernel-function parameters (CFConfig subset), reference include/read_configs.h:15-25
+struct KernelFn {
+    int   type;          // 0 polynomial, 1 gaussian
+    float offset;
+    int   power;
+    float sigma;
+    float lambda;
+};
+
+// entry of the de-rotation table: inverse affine matrix of cv::warpAffine for one candidate angle
+struct RotEntry {
+    double m[6];
+};
+
+// Geometry of one "plane family": real plane rows x cols (column-major: a line = one column of `rows`
+// contiguous floats), spectrum stored k-major: [rows/2+1][cols] float2 (cols contiguous).
+struct PlaneGeom {
+    int rows, cols;      // rows even
+    int hr;              // rows/2+1
+};
+
+bool fft_half_supported(int h);   // rows/2 instantiated?
+bool fft_line_supported(int n);   // cols instantiated?
+
+struct Tables {
+    const float2* tw_half;   // W_h,  h = rows/2   (h entries)
+    const float2* tw_full;   // W_{2h} first h entries (r2c / c2r post-twiddles)
+    const float2* tw_cols;   // W_cols (cols entries)
+};
+
+// ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
+void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,
+                   int H, int W);
+
+// ---- A-type: lines along `rows` (r2c / c2r), transposed spectrum access ----
+// forward from a real plane: src plane index = src_idx ? src_idx[item] : item
+void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride,
+                        const int* src_idx, float2* dst, size_t dst_stride);
+// forward from the de-rotated image (RotateArray fused into the load)
+void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride,
+                      const int* img_slot, const RotEntry* rot_tab, const int* rot_index,
+                      float2* dst, size_t dst_stride);
+// forward from polar(fftshift(RemoveZeroComponent(p))) (gather fused into the load); g = polar geometry
+void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* p, size_t p_stride,
+                        int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride);
+// inverse to a real plane, scaled by 1/(rows*cols)
+void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                       float* dst, size_t dst_stride);
+// inverse -> /(rows*cols) -> kernel function -> running max|k| -> forward; in place on `buf`.
+// buf holds 2 planes per item (zz then xz), maxbuf 2 uints per item (float bits, zeroed by caller),
+// energy 2 floats per item (gaussian: sum|X|^2, sum|Z|^2 over the half spectrum).
+void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, float2* buf, size_t item_stride,
+                             size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy);
+// inverse -> /(rows*cols) -> arg-max + moments partials
+void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                         Partial* partials, int partial_stride);
+int  argmax_blocks(PlaneGeom g);
+
+// ---- B-type: contiguous spectrum lines along `cols` ----
+void launch_B_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                  float2* dst_base, size_t dst_stride, const int* dst_slot);
+void launch_B_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                  float2* dst, size_t dst_stride);
+// F = fwd(src) -> dst (slot), |F| -> inverse -> tmp
+void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                          float2* dstF_base, size_t dstF_stride, const int* dst_slot,
+                          float2* tmp, size_t tmp_stride);
+// out planes (item_stride apart, plane_stride between zz and xz): inv(|Z|^2), inv(X conj Z).
+// X: x_fwd ? fwd(xsrc line) : xsrc line.  X plane index = x_idx ? x_idx[item] : item.
+void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
+                      const float2* xsrc, size_t x_stride, const int* x_idx,
+                      const float2* zsrc, size_t z_stride, const int* z_idx,
+                      float2* out, size_t item_stride, size_t plane_stride);
+// G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
+void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
+                        size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride);
+
+// half-spectrum energies for the gaussian kernel: energy[item] = {sum|X|^2, sum|Z|^2}
+void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, size_t x_stride, const int* x_idx,
+                   const float2* zsrc, size_t z_stride, const int* z_idx, float* energy);
+
+// reduce partials -> SurfaceResult per item
+void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials,
+                     SurfaceResult* out);
+// rot_index[t] = variant[t] * PD + (res[pair[t]].idx % PD)   (row of the rotation arg-max selects the angle)
+void launch_rot_index(hipStream_t s, int n_items, const SurfaceResult* rot_res, const int* pair, const int* variant,
+                      int PD, int* rot_index);
+
+// debug: the two gathers on their own (no FFT)
+void launch_dbg_rot(hipStream_t s, const float* img, const RotEntry& R, float* out, int H, int W);
+void launch_dbg_polar(hipStream_t s, const float* p, const uint32_t* tab, float* out, int H, int W, int PD, int PC);
+
+// layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]
+void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols);
+
+}  // namespace kcc

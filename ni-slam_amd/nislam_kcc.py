@@ -1,0 +1,248 @@
+"""ctypes binding of libnislam_kcc_hip.so (C ABI: include/nislam_kcc.h).
+
+Python is only the test / bench harness language here; the product is the shared library.  The
+binding mirrors the reference's CorrelationFlow interface (include/correlation_flow.h:8-33):
+``CorrelationFlow(cfg, H, W)``, ``ComputeIntermedium``, ``ComputePose``.  There is NO CPU fallback:
+if the library or a HIP device is missing every entry point raises.
+
+Array conventions: a reference (Eigen, column-major) rows x cols array is
+a C-order numpy array of shape (cols, rows); u8 images are (rows, cols).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnislam_kcc_hip.so")
+
+NIK_OK = 0
+NIK_ERR_INVALID_ARG, NIK_ERR_UNSUPPORTED_SIZE, NIK_ERR_INVALID_KERNEL = -1, -2, -3
+NIK_ERR_HIP, NIK_ERR_CAPACITY, NIK_ERR_NOT_READY = -4, -5, -6
+
+EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_stream", "nik_synchronize",
+           "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
+           "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
+           "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar"]
+
+
+class NikConfig(C.Structure):
+    """mirrors CFConfig (reference include/read_configs.h:15-25)"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("lambda_", C.c_float), ("kernel", C.c_int),
+                ("sigma", C.c_float), ("offset", C.c_float), ("power", C.c_int),
+                ("rotation_divisor", C.c_int), ("rotation_channel", C.c_int)]
+
+
+class NikPoseResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("info", C.c_double * 3),
+                ("rot_row", C.c_int32), ("rot_col", C.c_int32),
+                ("trans_row", C.c_int32 * 2), ("trans_col", C.c_int32 * 2),
+                ("psr_rot", C.c_float), ("psr_trans", C.c_float * 2),
+                ("degree_final", C.c_float), ("chosen", C.c_int32), ("n_hyp", C.c_int32)]
+
+    def as_dict(self):
+        return dict(pose=list(self.pose), info=list(self.info), rot_row=self.rot_row, rot_col=self.rot_col,
+                    trans_row=list(self.trans_row), trans_col=list(self.trans_col), psr_rot=float(self.psr_rot),
+                    psr_trans=[float(v) for v in self.psr_trans], degree_final=float(self.degree_final),
+                    chosen=self.chosen, n_hyp=self.n_hyp)
+
+
+class NikError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nislam_kcc error %d: %s" % (code, msg))
+        self.code = code
+
+
+def default_config(kernel=0, rotation_divisor=720, rotation_channel=480, power=3):
+    """values of reference configs/config_ntu.yaml:6-17"""
+    return NikConfig(width=640, height=480, lambda_=0.1, kernel=kernel, sigma=0.2, offset=0.1, power=power,
+                     rotation_divisor=rotation_divisor, rotation_channel=rotation_channel)
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NikError(NIK_ERR_HIP, "libnislam_kcc_hip.so not built -- run __graft_entry__.build()")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so (soname libamdhip64.so.7).
+        # If torch is going to be used in this process (device buffers, torch.distributed) it has to be
+        # loaded FIRST so that our DT_NEEDED libamdhip64.so.7 binds to the copy already in the process;
+        # loading /opt/rocm's runtime first and torch's second leaves torch without a device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(LIB_PATH)
+        P, I = C.c_void_p, C.c_int
+        L.nik_create.argtypes = [C.POINTER(NikConfig), I, I, I, I, I, C.POINTER(P)]
+        L.nik_destroy.argtypes = [P]
+        L.nik_destroy.restype = None
+        L.nik_last_error.argtypes = [P]
+        L.nik_last_error.restype = C.c_char_p
+        L.nik_get_dims.argtypes = [P, C.POINTER(I * 6)]
+        L.nik_stream.argtypes = [P]
+        L.nik_stream.restype = P
+        L.nik_synchronize.argtypes = [P]
+        L.nik_intermedium_u8.argtypes = [P, P, I, I]
+        L.nik_intermedium_f32.argtypes = [P, P, I]
+        L.nik_intermedium_batch_dev.argtypes = [P, I, P, P]
+        L.nik_frame_export.argtypes = [P, I, P, P, P]
+        L.nik_frame_import.argtypes = [P, I, P, P, P]
+        L.nik_pose.argtypes = [P, I, I, I, P, P, P]
+        L.nik_pose_batch.argtypes = [P, I, P, P, I, P]
+        L.nik_track_batch_dev.argtypes = [P, I, P, P, P, I, P, I]
+        L.nik_match.argtypes = [P, I, I, P, P, P, P]
+        L.nik_dbg_fft.argtypes = [P, I, P, P]
+        L.nik_dbg_ifft.argtypes = [P, I, P, P]
+        L.nik_dbg_rotate.argtypes = [P, I, I, P]
+        L.nik_dbg_polar.argtypes = [P, P, P]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _i32(seq):
+    return np.ascontiguousarray(np.asarray(seq, dtype=np.int32))
+
+
+class CorrelationFlow:
+    """MI355X CorrelationFlow.  Frames live in device slots (the analogue of reference Frame's spectra)."""
+
+    def __init__(self, cfg, image_height, image_width, max_batch=8, max_frames=64, device=0):
+        self._L = load()
+        self._ctx = C.c_void_p()
+        rc = self._L.nik_create(C.byref(cfg), int(image_height), int(image_width), int(max_batch), int(max_frames),
+                                int(device), C.byref(self._ctx))
+        if rc:
+            self._ctx = None
+            raise NikError(rc, self._L.nik_last_error(None).decode())
+        self.cfg, self.H, self.W = cfg, int(image_height), int(image_width)
+        self.PD, self.PC = cfg.rotation_divisor, cfg.rotation_channel
+        self.max_batch, self.max_frames = max_batch, max_frames
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._L.nik_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._ctx).decode())
+
+    @property
+    def stream(self):
+        return self._L.nik_stream(self._ctx)
+
+    def synchronize(self):
+        self._chk(self._L.nik_synchronize(self._ctx))
+
+    # ---- ComputeIntermedium ------------------------------------------------------------------
+    def intermedium_u8(self, gray, dst):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        assert gray.shape == (self.H, self.W)
+        self._chk(self._L.nik_intermedium_u8(self._ctx, _p(gray), self.W, int(dst)))
+
+    def intermedium_f32(self, image, dst):
+        image = np.ascontiguousarray(image, np.float32)
+        assert image.shape == (self.W, self.H)
+        self._chk(self._L.nik_intermedium_f32(self._ctx, _p(image), int(dst)))
+
+    def intermedium_batch_dev(self, d_gray_ptr, n, dst):
+        dst = _i32(dst)
+        self._chk(self._L.nik_intermedium_batch_dev(self._ctx, int(n), C.c_void_p(int(d_gray_ptr)), _p(dst)))
+
+    def ComputeIntermedium(self, image, dst=0):
+        """reference signature ComputeIntermedium(image, fft_result&, fft_polar&): returns the two spectra."""
+        self.intermedium_f32(image, dst)
+        _, f, p = self.frame_export(dst, image=False)
+        return f, p
+
+    def frame_export(self, f, image=True, spectra=True):
+        img = np.empty((self.W, self.H), np.float32) if image else None
+        fr = np.empty((self.W, self.H // 2 + 1), np.complex64) if spectra else None
+        fp = np.empty((self.PC, self.PD // 2 + 1), np.complex64) if spectra else None
+        self._chk(self._L.nik_frame_export(self._ctx, int(f), _p(img), _p(fr), _p(fp)))
+        return img, fr, fp
+
+    def frame_import(self, f, image=None, fft_result=None, fft_polar=None):
+        image = None if image is None else np.ascontiguousarray(image, np.float32)
+        fft_result = None if fft_result is None else np.ascontiguousarray(fft_result, np.complex64)
+        fft_polar = None if fft_polar is None else np.ascontiguousarray(fft_polar, np.complex64)
+        self._chk(self._L.nik_frame_import(self._ctx, int(f), _p(image), _p(fft_result), _p(fft_polar)))
+
+    # ---- ComputePose -------------------------------------------------------------------------
+    def pose(self, key, cur, not_large_rotation=True):
+        pose, info, res = np.zeros(3), np.zeros(3), NikPoseResult()
+        self._chk(self._L.nik_pose(self._ctx, int(key), int(cur), int(bool(not_large_rotation)), _p(pose), _p(info),
+                                   C.addressof(res)))
+        return pose, info, res.as_dict()
+
+    def ComputePose(self, last_fft_result, image, last_fft_polar, fft_polar, not_large_rotation, key_slot=0, cur_slot=1):
+        """reference signature: spectra/image passed by value (host arrays in the reference layouts)."""
+        self.frame_import(key_slot, None, last_fft_result, last_fft_polar)
+        # the current frame's fft_result is not an input of ComputePose; import a zero spectrum placeholder
+        self.frame_import(cur_slot, image, np.zeros((self.W, self.H // 2 + 1), np.complex64), fft_polar)
+        # the key slot needs an image flag too (never read by ComputePose)
+        self.frame_import(key_slot, np.zeros((self.W, self.H), np.float32), None, None)
+        return self.pose(key_slot, cur_slot, not_large_rotation)
+
+    def pose_batch(self, keys, curs, not_large_rotation=True):
+        keys, curs = _i32(keys), _i32(curs)
+        n = len(keys)
+        res = (NikPoseResult * n)()
+        self._chk(self._L.nik_pose_batch(self._ctx, n, _p(keys), _p(curs), int(bool(not_large_rotation)),
+                                         C.cast(res, C.c_void_p)))
+        return [r.as_dict() for r in res]
+
+    def track_batch_dev(self, d_gray_ptr, keys, cur_dst, not_large_rotation=True, sync=True, res=None):
+        keys, cur_dst = _i32(keys), _i32(cur_dst)
+        n = len(keys)
+        if res is None:
+            res = (NikPoseResult * n)()
+        self._chk(self._L.nik_track_batch_dev(self._ctx, n, C.c_void_p(int(d_gray_ptr)), _p(keys), _p(cur_dst),
+                                              int(bool(not_large_rotation)), C.cast(res, C.c_void_p), int(bool(sync))))
+        return res
+
+    def match(self, query, cands):
+        cands = _i32(cands)
+        n = len(cands)
+        res = (NikPoseResult * max(n, 1))()
+        best, best_res = C.c_int(-1), NikPoseResult()
+        self._chk(self._L.nik_match(self._ctx, int(query), n, _p(cands), C.addressof(best), C.cast(res, C.c_void_p),
+                                    C.addressof(best_res)))
+        return best.value, [res[i].as_dict() for i in range(n)], best_res.as_dict()
+
+    # ---- debug taps --------------------------------------------------------------------------
+    def dbg_fft(self, x, which=0):
+        x = np.ascontiguousarray(x, np.float32)
+        cols, rows = x.shape
+        out = np.empty((cols, rows // 2 + 1), np.complex64)
+        self._chk(self._L.nik_dbg_fft(self._ctx, int(which), _p(x), _p(out)))
+        return out
+
+    def dbg_ifft(self, xf, which=0):
+        xf = np.ascontiguousarray(xf, np.complex64)
+        cols, hr = xf.shape
+        out = np.empty((cols, (hr - 1) * 2), np.float32)
+        self._chk(self._L.nik_dbg_ifft(self._ctx, int(which), _p(xf), _p(out)))
+        return out
+
+    def dbg_rotate(self, slot, degree2):
+        out = np.empty((self.W, self.H), np.float32)
+        self._chk(self._L.nik_dbg_rotate(self._ctx, int(slot), int(degree2), _p(out)))
+        return out
+
+    def dbg_polar(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty((self.PC, self.PD), np.float32)
+        self._chk(self._L.nik_dbg_polar(self._ctx, _p(x), _p(out)))
+        return out

@@ -1,0 +1,63 @@
+"""Shared helpers of the parity tests."""
+import importlib.util
+import math
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "ni-slam_amd")
+
+SMALL = dict(H=60, W=80, PD=120, PC=80)          # quick geometry (every FFT length instantiated)
+FULL = dict(H=480, W=640, PD=720, PC=480)        # reference configs/config_ntu.yaml
+
+
+def load_module(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+_nik = None
+
+
+def nik():
+    """the ctypes binding of the HIP library (ni-slam_amd/nislam_kcc.py; the directory name is not importable)"""
+    global _nik
+    if _nik is None:
+        _nik = load_module("nislam_kcc", os.path.join(PKG, "nislam_kcc.py"))
+    return _nik
+
+
+def ang_diff(a, b):
+    d = (a - b) % (2 * math.pi)
+    return min(d, 2 * math.pi - d)
+
+
+# relative gap between the rotation arg-max and its 180-degree mirror below which the two peaks are a
+# rounding-noise tie (the polar source is point-symmetric; see DESIGN.md "The 180-degree rotation tie").
+ROT_TIE_REL = 1e-3
+
+
+def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3):
+    """gpu: dict from NikPoseResult.as_dict(); ora_*: oracle outputs.  Returns (ok, exact_rot, message).
+
+    Rule: translation arg-max indices bit-exact; rotation arg-max bit-exact unless the oracle's own two
+    mirror peaks are within ROT_TIE_REL of each other, in which case row may differ by PD/2 (same rotation
+    modulo 180 deg, decided by FFT rounding noise in the reference itself); theta equal modulo 2*pi;
+    PSR within psr_rtol."""
+    msgs = []
+    exact_rot = gpu["rot_row"] == ora_dbg["rot_row"] and gpu["rot_col"] == ora_dbg["rot_col"]
+    if not exact_rot:
+        gap = abs(ora_dbg["rot_peak"] - ora_dbg["rot_mirror"]) / max(abs(ora_dbg["rot_peak"]), 1e-30)
+        mirror = gpu["rot_col"] == ora_dbg["rot_col"] and (gpu["rot_row"] - ora_dbg["rot_row"]) % PD == PD // 2
+        if not (mirror and gap < ROT_TIE_REL):
+            msgs.append("rot argmax gpu=(%d,%d) oracle=(%d,%d) gap=%.2e" % (
+                gpu["rot_row"], gpu["rot_col"], ora_dbg["rot_row"], ora_dbg["rot_col"], gap))
+    if gpu["pose"][0] != ora_pose[0] or gpu["pose"][1] != ora_pose[1]:
+        msgs.append("translation gpu=%s oracle=%s" % (gpu["pose"][:2], list(ora_pose[:2])))
+    if ang_diff(gpu["pose"][2], ora_pose[2]) > 1e-6:
+        msgs.append("theta gpu=%r oracle=%r" % (gpu["pose"][2], ora_pose[2]))
+    for k in (0, 2):
+        if abs(gpu["info"][k] - ora_info[k]) > psr_rtol * abs(ora_info[k]):
+            msgs.append("info[%d] gpu=%r oracle=%r" % (k, gpu["info"][k], ora_info[k]))
+    return (not msgs), exact_rot, "; ".join(msgs)

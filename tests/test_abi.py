@@ -1,0 +1,71 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every
+symbol include/nislam_kcc.h declares; without a GPU every entry point fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from kcc_helpers import PKG, ROOT, SMALL, load_module, nik
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    build = load_module("nislam_build", os.path.join(PKG, "build.py"))
+    return build.build()
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "nislam_kcc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(nik_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(lib_path):
+    L = ctypes.CDLL(lib_path)
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+    assert sorted(nik().EXPORTS) == names, "python binding and header disagree"
+
+
+def test_config_struct_mirrors_cfconfig():
+    N = nik()
+    fields = [f[0] for f in N.NikConfig._fields_]
+    assert fields == ["width", "height", "lambda_", "kernel", "sigma", "offset", "power", "rotation_divisor",
+                      "rotation_channel"]                      # reference include/read_configs.h:15-25 order
+    assert ctypes.sizeof(N.NikConfig) == 36
+    assert ctypes.sizeof(N.NikPoseResult) == 3 * 8 + 3 * 8 + 4 * 2 + 4 * 4 + 4 * 3 + 4 + 4 + 4
+
+
+def test_no_oracle_on_product_path():
+    """the product path must not reach into oracle/ (a CPU fallback would void every parity claim)"""
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(root, f), errors="ignore").read()
+                assert "kcc_oracle" not in src and "np_restatement" not in src, f
+
+
+def test_fails_loudly_without_gpu(lib_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    N = nik()
+    with pytest.raises(N.NikError) as e:
+        N.CorrelationFlow(N.default_config(rotation_divisor=SMALL["PD"], rotation_channel=SMALL["PC"]), SMALL["H"], SMALL["W"])
+    assert e.value.code == N.NIK_ERR_HIP and "no CPU fallback" in str(e.value)
+
+
+def test_argument_validation_precedes_device_use(lib_path):
+    N = nik()
+    L = N.load()
+    ctx = ctypes.c_void_p()
+    cfg = N.default_config()
+    assert L.nik_create(None, 480, 640, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_INVALID_ARG
+    assert L.nik_create(ctypes.byref(cfg), 481, 640, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_UNSUPPORTED_SIZE
+    assert L.nik_create(ctypes.byref(cfg), 480, 642, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_UNSUPPORTED_SIZE
+    assert L.nik_create(ctypes.byref(cfg), 480, 640, 0, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_INVALID_ARG
+    assert b"even" in L.nik_last_error(None) or b"positive" in L.nik_last_error(None)
+    assert L.nik_synchronize(None) == N.NIK_ERR_INVALID_ARG

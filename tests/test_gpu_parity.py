@@ -1,0 +1,248 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Tolerances: arg-max indices bit-exact (see kcc_helpers.check_pose_parity for the documented 180-degree
+rotation tie); gathers bit-exact; FFT-derived float planes within 2e-5 of the plane's max |value|
+(float32 FFT rounding); PSR within 2e-3 relative.
+"""
+import numpy as np
+import pytest
+
+import synth
+from kcc_helpers import FULL, SMALL, check_pose_parity, nik
+from oracle import kcc_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+GEOMS = [pytest.param(SMALL, id="60x80"), pytest.param(FULL, id="480x640")]
+
+
+def _mk(geom, kernel=0, max_batch=8, max_frames=32, power=3):
+    N = nik()
+    cfg = N.default_config(kernel=kernel, rotation_divisor=geom["PD"], rotation_channel=geom["PC"], power=power)
+    ocfg = ko.default_config(kernel=kernel, rotation_divisor=geom["PD"], rotation_channel=geom["PC"], power=power)
+    cf = N.CorrelationFlow(cfg, geom["H"], geom["W"], max_batch=max_batch, max_frames=max_frames)
+    orc = ko.Oracle(ocfg, geom["H"], geom["W"])
+    return cf, orc, ocfg
+
+
+def _relmax(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_fft_and_ifft_match_oracle(geom):
+    cf, orc, _ = _mk(geom)
+    rng = np.random.default_rng(1)
+    for which, (rows, cols) in enumerate([(geom["H"], geom["W"]), (geom["PD"], geom["PC"])]):
+        x = rng.random((cols, rows), dtype=np.float32)
+        xf = cf.dbg_fft(x, which)
+        ref = orc.fft(x)
+        assert _relmax(xf, ref) < 2e-6, "forward FFT (which=%d)" % which
+        back = cf.dbg_ifft(ref, which)
+        assert np.abs(back - x).max() < 2e-6, "inverse FFT (which=%d)" % which
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_fft_known_answers(geom):
+    """analytic KATs: impulse at the centre -> (-1)^(k+l); constant -> single DC bin."""
+    cf, _, _ = _mk(geom)
+    H, W = geom["H"], geom["W"]
+    x = np.zeros((W, H), np.float32)
+    x[W // 2, H // 2] = 1
+    xf = cf.dbg_fft(x, 0)
+    l, k = np.meshgrid(np.arange(W), np.arange(H // 2 + 1), indexing="ij")
+    assert np.abs(xf - ((-1.0) ** (k + l))).max() < 1e-5
+    xf = cf.dbg_fft(np.ones((W, H), np.float32), 0)
+    assert abs(xf[0, 0] - H * W) < 1e-3 * H * W
+    xf[0, 0] = 0
+    assert np.abs(xf).max() < 1e-2
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_polar_gather_bit_exact(geom):
+    cf, orc, _ = _mk(geom)
+    x = np.random.default_rng(2).random((geom["W"], geom["H"]), dtype=np.float32)
+    got = cf.dbg_polar(x)
+    ref = orc.polar(orc.fftshift(orc.remove_zero(x)))
+    assert np.array_equal(got, ref)
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_rotate_gather_bit_exact(geom):
+    cf, orc, _ = _mk(geom)
+    img = synth.canvas(3, geom["H"], geom["W"])[: geom["H"], : geom["W"]]
+    cf.intermedium_u8(img, 0)
+    x = orc.normalize_u8(img)
+    got_img, _, _ = cf.frame_export(0, spectra=False)
+    assert np.array_equal(got_img, x), "u8 -> f32 conversion"
+    for deg2 in (0, 1, -1, 15, -37, 180, 359, -360, 700, -719):
+        got = cf.dbg_rotate(0, deg2)
+        ref = orc.rotate(x, deg2 * 0.5)
+        assert np.array_equal(got, ref), "RotateArray(%g deg)" % (deg2 * 0.5)
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_intermedium_matches_oracle(geom):
+    cf, orc, _ = _mk(geom)
+    _, cur = synth.make_pair(4, geom["H"], geom["W"], 3, -5, 2.0)
+    cf.intermedium_u8(cur, 1)
+    _, f, p = cf.frame_export(1)
+    rf, rp = orc.intermedium(orc.normalize_u8(cur))
+    assert _relmax(f, rf) < 2e-6
+    assert _relmax(p, rp) < 2e-5
+    # the f32 entry point (reference ComputeIntermedium signature) gives the same spectra
+    f2, p2 = cf.ComputeIntermedium(orc.normalize_u8(cur), dst=2)
+    assert np.array_equal(f2, f) and np.array_equal(p2, p)
+    cf.close()
+
+
+def _pairs(geom, n, seed0):
+    return synth.make_batch(n, geom["H"], geom["W"], seed0=seed0)
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("small_rot", [True, False], ids=["small_rot", "large_rot"])
+def test_pose_parity(geom, small_rot):
+    n = 6 if geom is FULL else 12
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
+    keys, curs, motions = _pairs(geom, n, 100)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), small_rot)
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, small_rot)
+    exact = 0
+    for i in range(n):
+        ok, ex, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], geom["PD"])
+        assert ok, "pair %d motion %s: %s" % (i, motions[i], msg)
+        exact += ex
+        assert res[i]["trans_row"][0] == dbgs[i]["trans_row"][0] and res[i]["trans_col"][0] == dbgs[i]["trans_col"][0]
+    # single-pair entry point agrees with the batch
+    pose, info, r0 = cf.pose(0, n, small_rot)
+    assert r0 == res[0] and list(pose) == res[0]["pose"]
+    print("rotation arg-max bit-identical on %d/%d pairs" % (exact, n))
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_known_motion_recovered(geom):
+    """KAT: a pure window shift (dy,dx) yields pose=(dx,dy,0) exactly (SURVEY 8a conventions)."""
+    cf, _, _ = _mk(geom)
+    H, W = geom["H"], geom["W"]
+    for j, (dy, dx) in enumerate([(0, 0), (3, -4), (-H // 10, W // 10)]):
+        k, c = synth.make_pair(7 + j, H, W, dy, dx, 0.0)
+        cf.intermedium_u8(k, 0)
+        cf.intermedium_u8(c, 1)
+        pose, info, r = cf.pose(0, 1, True)
+        assert (pose[0], pose[1]) == (dx, dy) and abs(pose[2]) % (2 * np.pi) < 1e-9, (dy, dx, pose)
+        assert info[0] > 15 and info[2] > 15
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_track_batch_dev(geom):
+    """the bench unit: device-resident u8 batch -> intermedium + pose in one call."""
+    import torch
+    n = 4 if geom is FULL else 8
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 300)
+    dk = torch.from_numpy(keys).cuda()
+    dc = torch.from_numpy(curs).cuda()
+    torch.cuda.synchronize()
+    cf.intermedium_batch_dev(dk.data_ptr(), n, list(range(n)))
+    res = cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True)
+    for i in range(n):
+        ok, _, msg = check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], geom["PD"])
+        assert ok, msg
+    # asynchronous form: results appear after synchronize()
+    res2 = cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=False)
+    cf.synchronize()
+    assert [r.as_dict() for r in res2] == [r.as_dict() for r in res]
+    # the current frames were stored and can serve as keys (map_builder.cc:99-106)
+    _, f, p = cf.frame_export(n)
+    rf, rp = orc.intermedium(orc.normalize_u8(curs[0]))
+    assert _relmax(f, rf) < 2e-6 and _relmax(p, rp) < 2e-5
+    cf.close()
+
+
+def test_match_loop_closure():
+    """LoopClosure::FindLoopClosure's candidate loop (loop_closure.cc:40-66)."""
+    geom = SMALL
+    n = 5
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=n + 1)
+    H, W = geom["H"], geom["W"]
+    cv = synth.canvas(42, H, W)
+    query = synth.window(cv, H, W, 2, -3, 0.0)
+    cands = [synth.window(synth.canvas(50 + i, H, W), H, W) for i in range(n)]
+    cands[3] = synth.window(cv, H, W)                      # the true loop candidate
+    for i in range(n):
+        cf.intermedium_u8(cands[i], i)
+    cf.intermedium_u8(query, n)
+    best, res, best_res = cf.match(n, list(range(n)))
+    assert best == 3 and best_res == res[3]
+    assert (best_res["pose"][0], best_res["pose"][1]) == (-3, 2)
+    qf = orc.normalize_u8(query)
+    _, qp = orc.intermedium(qf)
+    sums = []
+    for i in range(n):
+        kf, kp = orc.intermedium(orc.normalize_u8(cands[i]))
+        pose, info, dbg = orc.compute_pose(kf, qf, kp, qp, False)
+        ok, _, msg = check_pose_parity(res[i], pose, info, dbg, geom["PD"], psr_rtol=5e-3)
+        if i == 3:
+            assert ok, msg
+        sums.append(info.sum())
+    assert int(np.argmax(sums)) == 3
+    assert cf.match(n, [])[0] == -1
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", [pytest.param(SMALL, id="60x80")])
+def test_gaussian_kernel_parity(geom):
+    n = 4
+    cf, orc, ocfg = _mk(geom, kernel=1, max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 500)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), True)
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True)
+    for i in range(n):
+        ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], geom["PD"], psr_rtol=1e-2)
+        assert ok, msg
+    cf.close()
+
+
+def test_error_behaviour():
+    N = nik()
+    # invalid kernel id: the reference throws std::invalid_argument at EstimateTrans time (correlation_flow.cc:167-168)
+    cfg = N.default_config(kernel=7, rotation_divisor=SMALL["PD"], rotation_channel=SMALL["PC"])
+    cf = N.CorrelationFlow(cfg, SMALL["H"], SMALL["W"])
+    img = synth.canvas(1, SMALL["H"], SMALL["W"])[: SMALL["H"], : SMALL["W"]]
+    cf.intermedium_u8(img, 0)           # ComputeIntermedium does not look at the kernel id
+    cf.intermedium_u8(img, 1)
+    with pytest.raises(N.NikError) as e:
+        cf.pose(0, 1, True)
+    assert e.value.code == N.NIK_ERR_INVALID_KERNEL and "invalid kernel" in str(e.value)
+    with pytest.raises(N.NikError) as e:
+        cf.pose(0, 5, True)             # kernel check comes first, like the reference's throw
+    cf.close()
+    good = N.default_config(rotation_divisor=SMALL["PD"], rotation_channel=SMALL["PC"])
+    cf = N.CorrelationFlow(good, SMALL["H"], SMALL["W"], max_batch=2, max_frames=4)
+    with pytest.raises(N.NikError) as e:
+        cf.pose(0, 1, True)             # empty slots
+    assert e.value.code == N.NIK_ERR_NOT_READY
+    with pytest.raises(N.NikError) as e:
+        cf.intermedium_u8(img, 9)
+    assert e.value.code == N.NIK_ERR_CAPACITY
+    with pytest.raises(N.NikError) as e:
+        cf.pose_batch([0, 0, 0], [1, 1, 1], True)
+    assert e.value.code == N.NIK_ERR_CAPACITY
+    cf.close()
+    with pytest.raises(N.NikError) as e:
+        N.CorrelationFlow(good, 61, 80)                    # odd height: the reference silently mis-sizes (:67); we refuse
+    assert e.value.code == N.NIK_ERR_UNSUPPORTED_SIZE
