@@ -1,0 +1,166 @@
+#!/usr/bin/env python
+"""bench.py -- frame-pairs/s of the KCC front end (ComputeIntermedium(current) + ComputePose(key, current,
+not_large_rotation=true)) on 640x480 synthetic ground texture, inputs resident in HBM.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+A step = one pass of the hot path over a batch of B frame pairs per GPU (weak scaling: B per rank fixed).
+Multi-GPU: one process per GPU (torch.distributed, RCCL); pairs shard across ranks with no data-path
+collective; one 4-double all-reduce per step carries the residual/PSR statistics (north_star).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+H, W, PD, PC = 480, 640, 720, 480
+# algorithmic HBM bytes of one 640x480 frame pair (every 2-D FFT = 1 read + 1 write of its
+# planes, all pointwise work fused, Kzz NOT cached -- the reference recomputes it per pair).
+BYTES_PER_PAIR = 40.63e6
+HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated (tiled to --batch)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import synth
+    from kcc_helpers import check_pose_parity, nik
+    N = nik()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B, U = args.batch, min(args.unique, args.batch)
+    keys_u8, curs_u8, motions = synth.make_batch(U, H, W, seed0=1000 * rank, max_shift=48, max_theta=10.0)
+    reps = (B + U - 1) // U
+    keys_b = np.tile(keys_u8, (reps, 1, 1))[:B]
+    curs_b = np.tile(curs_u8, (reps, 1, 1))[:B]
+    d_keys = torch.from_numpy(keys_b).to(dev)
+    d_curs = torch.from_numpy(curs_b).to(dev)
+    torch.cuda.synchronize()
+
+    cfg = N.default_config()
+    cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
+    key_slots = list(range(B))
+    cur_slots = list(range(B, 2 * B))
+    cf.intermedium_batch_dev(d_keys.data_ptr(), B, key_slots)       # keyframe spectra: prepared before the timed region
+    cf.synchronize()
+    stats = torch.zeros(4, dtype=torch.float64, device=dev)
+
+    def step():
+        res = cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=True)
+        if world > 1:
+            s = np.zeros(4)
+            for r in res:
+                s += (r.info[0], r.info[2], r.pose[0] ** 2 + r.pose[1] ** 2, 1.0)
+            stats.copy_(torch.from_numpy(s))
+            dist.all_reduce(stats)                                   # RCCL: [sum PSR_t, sum PSR_r, sum |t|^2, count]
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    cf.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    pairs_per_s = B * world / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel roofline: HIP events around every launch, on the launch stream, over extra timed steps
+        roof = None
+        kernels = []
+        if not args.no_profile:
+            cf.profile_enable(True)
+            psteps = max(2, min(args.steps, 5))
+            for _ in range(psteps):
+                cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=True)
+            st = cf.profile_read()
+            cf.profile_enable(False)
+            tot = sum(s["ms"] for s in st)
+            for s in sorted(st, key=lambda s: -s["ms"]):
+                avg_ms = s["ms"] / s["launches"]
+                bpl = s["bytes"] / s["launches"]
+                kernels.append(dict(name=s["name"], avg_ms=round(avg_ms, 4), share=round(s["ms"] / tot, 4),
+                                    bytes_per_launch=bpl, gbps=round(bpl / (avg_ms * 1e-3) / 1e9, 1)))
+            top = kernels[0]
+            ach = top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9
+            roof = dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
+                        frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=None, avg_ms=top["avg_ms"],
+                        bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
+        # ---- parity spot check of the last step against the oracle (not timed)
+        from oracle import kcc_oracle as ko
+        ocfg = ko.default_config()
+        ncheck = min(4, U)
+        poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys_b[:ncheck], curs_b[:ncheck], True, nthreads=ncheck)
+        parity_ok = all(check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], PD)[0] for i in range(ncheck))
+        # ---- CPU baseline: the oracle (a dependency-free port; the reference itself is unbuildable here)
+        cpu = None
+        if args.cpu_sample > 0:
+            ncores = os.cpu_count() or 1
+            ns = args.cpu_sample
+            reps_c = (ns + U - 1) // U
+            kk, cc = np.tile(keys_u8, (reps_c, 1, 1))[:ns], np.tile(curs_u8, (reps_c, 1, 1))[:ns]
+            _, _, _, secs_all = ko.track_pairs(ocfg, kk, cc, True, faithful=False, nthreads=min(ncores, ns))
+            n1 = max(1, min(4, ns))
+            _, _, _, secs_1 = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=False, nthreads=1)
+            _, _, _, secs_1f = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=True, nthreads=1)
+            cpu = dict(value=round(ns / secs_all, 2), unit="frame-pairs/s", cores=min(ncores, ns), kind="port",
+                       sample="%d pairs of the same 640x480 workload, lean mode, OpenMP over pairs" % ns,
+                       value_1thread=round(n1 / secs_1, 3), value_1thread_reference_faithful=round(n1 / secs_1f, 3),
+                       host_cpus=ncores)
+        out = {
+            "metric": "frame-pairs/s (corr-volume + pose solve) at 640x480", "value": round(pairs_per_s, 1),
+            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 640x480 mono, ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), "
+                                   "polynomial kernel, polar 720x480, Kzz not cached",
+                       "pairs_per_gpu_per_step": B, "unique_pairs": U, "parallelism": "pairs sharded x%d" % world},
+            "path_roofline": {"bytes_per_pair": BYTES_PER_PAIR, "achieved_GBps": round(pairs_per_s / world * BYTES_PER_PAIR / 1e9, 1),
+                              "frac_of_8TBps": round(pairs_per_s / world * BYTES_PER_PAIR / HBM_PEAK, 4)},
+            "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": bool(parity_ok), "kernels": kernels,
+        }
+        print(json.dumps(out))
+    cf.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

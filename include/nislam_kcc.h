@@ -131,6 +131,20 @@ int nik_track_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_fr
 int nik_match(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands,
               int* best, nik_pose_result* res /* n entries, may be NULL */, nik_pose_result* best_res);
 
+/* ---- measurement ---------------------------------------------------------------------------- */
+
+/* Per-kernel timing with HIP events recorded on nik_stream() around every hot-path launch.
+ * bytes = the launch's compulsory HBM traffic (its inputs read once + its outputs written once),
+ * summed over launches.  Enabling resets the accumulators; reading synchronises the stream. */
+typedef struct {
+    char    name[64];     /* kernel<length,mode> */
+    double  ms;           /* total device time of the launches */
+    int64_t launches;
+    double  bytes;
+} nik_stage_stat;
+int nik_profile_enable(nik_ctx* ctx, int enable);
+int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);
+
 /* ---- debug / parity taps (used by tests only) --------------------------------------------- */
 
 /* CorrelationFlow::FFT / IFFT (correlation_flow.cc:53-77) on host arrays in the reference layouts.

@@ -59,6 +59,13 @@ struct nik_ctx {
     uint32_t* polar_tab = nullptr;
     RotEntry* rot_tab = nullptr;         // [3][PD]
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
+    // per-stage HIP-event profiler (nik_profile_enable / nik_profile_read)
+    struct StageStat { std::string name; double ms = 0; long launches = 0; double bytes = 0; };
+    struct StageRec { int stage; hipEvent_t a, b; };
+    bool prof_on = false;
+    std::vector<StageStat> prof_stats;
+    std::vector<StageRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
     // pending asynchronous batch
     struct Pending { bool active = false; int n = 0; int n_hyp = 1; nik_pose_result* res = nullptr; } pending;
 };
@@ -202,18 +209,49 @@ KernelFn kernel_fn(const nik_ctx* c) {
     return fn;
 }
 
+// ---- stage profiler: brackets one kernel launch with HIP events on the launch stream -----------------
+struct Stage {
+    nik_ctx* c; int rec = -1;
+    Stage(nik_ctx* c_, const char* name, double bytes) : c(c_) {
+        if (!c->prof_on) return;
+        int id = -1;
+        for (size_t i = 0; i < c->prof_stats.size(); ++i) if (c->prof_stats[i].name == name) { id = (int)i; break; }
+        if (id < 0) { c->prof_stats.push_back({}); id = (int)c->prof_stats.size() - 1; c->prof_stats[id].name = name; }
+        c->prof_stats[id].launches += 1; c->prof_stats[id].bytes += bytes;
+        nik_ctx::StageRec r; r.stage = id;
+        for (hipEvent_t* e : { &r.a, &r.b }) {
+            if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) return;
+        }
+        (void)hipEventRecord(r.a, c->stream);
+        c->prof_recs.push_back(r); rec = (int)c->prof_recs.size() - 1;
+    }
+    ~Stage() { if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, c->stream); }
+};
+std::string kname(const char* base, int len, const char* mode) {
+    char b[64]; snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode); return b;
+}
+inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
+inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
+
 // ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
 // arena slots listed in d_idx[IX_DST].
 void enqueue_intermedium(nik_ctx* c, int n) {
     hipStream_t s = c->stream;
     const int* dst = didx(c, IX_DST);
-    launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img.real_elems, dst, c->tmpA, c->spec_max);
-    launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, c->tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
-                         c->gbuf, c->spec_max);
-    launch_A_inv_real(s, n, c->img.g, c->img.t, c->gbuf, c->spec_max, c->pplane, c->img.real_elems);
-    launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, c->pplane, c->img.real_elems, c->H, c->W, c->polar_tab,
-                       c->tmpA, c->spec_max);
-    launch_B_fwd(s, n, c->pol.g, c->pol.t, c->tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst);
+    const Family& I = c->img; const Family& P = c->pol;
+    { Stage st(c, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
+      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img.real_elems, dst, c->tmpA, c->spec_max); }
+    { Stage st(c, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
+      launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, c->tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
+                           c->gbuf, c->spec_max); }
+    { Stage st(c, kname("kA_inv", c->H / 2, "real").c_str(), n * (Cb(I) + Rb(I)));
+      launch_A_inv_real(s, n, c->img.g, c->img.t, c->gbuf, c->spec_max, c->pplane, c->img.real_elems); }
+    { Stage st(c, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, c->pplane, c->img.real_elems, c->H, c->W, c->polar_tab,
+                         c->tmpA, c->spec_max); }
+    { Stage st(c, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
+      launch_B_fwd(s, n, c->pol.g, c->pol.t, c->tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
 }
 
 // EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
@@ -224,11 +262,15 @@ void enqueue_estimate(nik_ctx* c, int n, Family& f, bool x_fwd, const float2* xs
     (void)hipMemsetAsync(c->maxbuf, 0, sizeof(unsigned) * 2 * n, s);
     if (c->cfg.kernel == 1 && !x_fwd)
         launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, c->energy);
-    launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, c->kbuf, item_stride, plane_stride);
-    launch_A_inv_kernel_fwd(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, kernel_fn(c), c->maxbuf, c->energy);
-    launch_B_solve_inv(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, c->maxbuf, c->cfg.lambda, c->gbuf, c->spec_max);
+    { Stage st(c, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
+      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, c->kbuf, item_stride, plane_stride); }
+    { Stage st(c, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
+      launch_A_inv_kernel_fwd(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, kernel_fn(c), c->maxbuf, c->energy); }
+    { Stage st(c, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
+      launch_B_solve_inv(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, c->maxbuf, c->cfg.lambda, c->gbuf, c->spec_max); }
     const int nb = argmax_blocks(f.g);
-    launch_A_inv_argmax(s, n, f.g, f.t, c->gbuf, c->spec_max, c->partials, c->partial_stride);
+    { Stage st(c, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
+      launch_A_inv_argmax(s, n, f.g, f.t, c->gbuf, c->spec_max, c->partials, c->partial_stride); }
     launch_finalize(s, n, c->partials, c->partial_stride, nb, out);
 }
 
@@ -253,8 +295,9 @@ int enqueue_pose(nik_ctx* c, int n, int not_large_rotation) {
         (rc = upload_idx(c, IX_TIMG, nt)) || (rc = upload_idx(c, IX_TKEY, nt))) return rc;
     launch_rot_index(s, nt, c->rot_res, didx(c, IX_PAIR), didx(c, IX_VARIANT), c->PD, didx(c, IX_ROTIDX));
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
-    launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(c, IX_TIMG), c->rot_tab,
-                     didx(c, IX_ROTIDX), c->tmpA, c->spec_max);
+    { Stage st(c, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
+      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(c, IX_TIMG), c->rot_tab,
+                       didx(c, IX_ROTIDX), c->tmpA, c->spec_max); }
     if (c->cfg.kernel == 1) {
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
         launch_B_fwd(s, nt, c->img.g, c->img.t, c->tmpA, c->spec_max, c->tmpA, c->spec_max, nullptr);
@@ -395,6 +438,8 @@ void nik_destroy(nik_ctx* c) {
     if (c->h_rot) (void)hipHostFree(c->h_rot);
     if (c->h_trans) (void)hipHostFree(c->h_trans);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->rot_tab);
+    for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     if (c->idx_event) (void)hipEventDestroy(c->idx_event);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -425,7 +470,8 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
     if ((rc = drain_pending(c)) || (rc = begin_idx(c))) return rc;
     for (int i = 0; i < n; ++i) { if ((rc = check_slot(c, dst[i], false))) return rc; hidx(c, IX_DST)[i] = dst[i]; }
     if ((rc = upload_idx(c, IX_DST, n))) return rc;
-    launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W);
+    { Stage st(c, "k_cvt_u8", n * (1.0 * c->img.real_elems + Rb(c->img)));
+      launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W); }
     enqueue_intermedium(c, n);
     HIP_TRY(c, hipGetLastError());
     for (int i = 0; i < n; ++i) c->slot_ready[dst[i]] = 3;
@@ -543,7 +589,8 @@ int nik_track_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const nik_fram
         hidx(c, IX_KEY)[i] = keys[i]; hidx(c, IX_CUR)[i] = cur_dst[i]; hidx(c, IX_DST)[i] = cur_dst[i];
     }
     if ((rc = upload_idx(c, IX_KEY, n)) || (rc = upload_idx(c, IX_CUR, n)) || (rc = upload_idx(c, IX_DST, n))) return rc;
-    launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W);
+    { Stage st(c, "k_cvt_u8", n * (1.0 * c->img.real_elems + Rb(c->img)));
+      launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W); }
     enqueue_intermedium(c, n);
     for (int i = 0; i < n; ++i) c->slot_ready[cur_dst[i]] = 3;
     if ((rc = enqueue_pose(c, n, not_large_rotation))) return rc;
@@ -569,6 +616,37 @@ int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* b
     }
     if (best) *best = b;
     if (best_res && b >= 0) *best_res = res[b];
+    return NIK_OK;
+}
+
+int nik_profile_enable(nik_ctx* c, int enable) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    int rc = drain_pending(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_recs) { c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b); }
+    c->prof_recs.clear(); c->prof_stats.clear();
+    c->prof_on = enable != 0;
+    return NIK_OK;
+}
+
+int nik_profile_read(nik_ctx* c, nik_stage_stat* out, int cap, int* n) {
+    if (!c || !n) return NIK_ERR_INVALID_ARG;
+    int rc = drain_pending(c);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& r : c->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_stats[r.stage].ms += ms;
+        c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b);
+    }
+    c->prof_recs.clear();
+    *n = (int)c->prof_stats.size();
+    for (int i = 0; i < *n && i < cap && out; ++i) {
+        memset(&out[i], 0, sizeof(out[i]));
+        strncpy(out[i].name, c->prof_stats[i].name.c_str(), sizeof(out[i].name) - 1);
+        out[i].ms = c->prof_stats[i].ms; out[i].launches = c->prof_stats[i].launches; out[i].bytes = c->prof_stats[i].bytes;
+    }
     return NIK_OK;
 }
 

@@ -23,7 +23,8 @@ NIK_ERR_HIP, NIK_ERR_CAPACITY, NIK_ERR_NOT_READY = -4, -5, -6
 EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_stream", "nik_synchronize",
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
-           "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar"]
+           "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
+           "nik_profile_enable", "nik_profile_read"]
 
 
 class NikConfig(C.Structure):
@@ -45,6 +46,10 @@ class NikPoseResult(C.Structure):
                     trans_row=list(self.trans_row), trans_col=list(self.trans_col), psr_rot=float(self.psr_rot),
                     psr_trans=[float(v) for v in self.psr_trans], degree_final=float(self.degree_final),
                     chosen=self.chosen, n_hyp=self.n_hyp)
+
+
+class NikStageStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("ms", C.c_double), ("launches", C.c_int64), ("bytes", C.c_double)]
 
 
 class NikError(RuntimeError):
@@ -100,6 +105,8 @@ def load():
         L.nik_dbg_ifft.argtypes = [P, I, P, P]
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
         L.nik_dbg_polar.argtypes = [P, P, P]
+        L.nik_profile_enable.argtypes = [P, I]
+        L.nik_profile_read.argtypes = [P, P, I, P]
         _lib = L
     return _lib
 
@@ -220,6 +227,17 @@ class CorrelationFlow:
         self._chk(self._L.nik_match(self._ctx, int(query), n, _p(cands), C.addressof(best), C.cast(res, C.c_void_p),
                                     C.addressof(best_res)))
         return best.value, [res[i].as_dict() for i in range(n)], best_res.as_dict()
+
+    # ---- measurement -------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._L.nik_profile_enable(self._ctx, int(bool(on))))
+
+    def profile_read(self):
+        out = (NikStageStat * 64)()
+        n = C.c_int(0)
+        self._chk(self._L.nik_profile_read(self._ctx, C.cast(out, C.c_void_p), 64, C.addressof(n)))
+        return [dict(name=out[i].name.decode(), ms=out[i].ms, launches=out[i].launches, bytes=out[i].bytes)
+                for i in range(min(n.value, 64))]
 
     # ---- debug taps --------------------------------------------------------------------------
     def dbg_fft(self, x, which=0):

@@ -69,3 +69,26 @@ def test_argument_validation_precedes_device_use(lib_path):
     assert L.nik_create(ctypes.byref(cfg), 480, 640, 0, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_INVALID_ARG
     assert b"even" in L.nik_last_error(None) or b"positive" in L.nik_last_error(None)
     assert L.nik_synchronize(None) == N.NIK_ERR_INVALID_ARG
+
+
+def _build_adaptor_test(lib_path, tmpdir):
+    import subprocess
+    exe = os.path.join(str(tmpdir), "adaptor_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "adaptor_test.cpp"),
+                           "-I", PKG, "-L", PKG, "-Wl,-rpath," + PKG, "-lnislam_kcc_hip", "-o", exe])
+    return exe
+
+
+def test_cpp_adaptor_compiles_without_eigen(lib_path, tmp_path):
+    """the CorrelationFlow drop-in (ni-slam_amd/correlation_flow_hip.h) compiles with g++ against the C ABI"""
+    exe = _build_adaptor_test(lib_path, tmp_path)
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_cpp_adaptor_runs(lib_path, tmp_path):
+    import subprocess
+    exe = _build_adaptor_test(lib_path, tmp_path)
+    for size in (["60", "80"], ["480", "640"]):
+        out = subprocess.run([exe] + size, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ADAPTOR TEST OK" in out.stdout, out.stdout + out.stderr
