@@ -149,6 +149,8 @@ int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);
 
 /* CorrelationFlow::FFT / IFFT (correlation_flow.cc:53-77) on host arrays in the reference layouts.
  * which: 0 = image geometry (H x W), 1 = polar geometry (PD x PC). */
+/* performance ablation of the B-type kernels (results become garbage): 1 no loads, 2 no stores, 4 no FFT */
+int nik_dbg_set_ablate(int flags);
 int nik_dbg_fft (nik_ctx* ctx, int which, const float* x_colmajor, float* xf_out);
 int nik_dbg_ifft(nik_ctx* ctx, int which, const float* xf, float* x_out);
 /* RotateArray (utils.cc:154-161) of slot f's image by `degree2`/2 degrees (degree2 = 2*degree, integer). */

@@ -22,7 +22,7 @@ struct Family {                 // one plane geometry with its tables
     Tables t{};
     size_t real_elems = 0;      // rows*cols
     size_t spec_elems = 0;      // hr*cols
-    float2* d_tw_half = nullptr; float2* d_tw_full = nullptr; float2* d_tw_cols = nullptr;
+    float2* d_tw[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
 }  // namespace
@@ -94,18 +94,43 @@ std::vector<float2> twiddles(int n, int count) {
     return t;
 }
 
+// pass-twiddle table of one plan and direction ("Twiddle table layout" in kcc_fft2.h); evaluated in double
+std::vector<float2> plan_table(const PlanDesc& d, bool inv) {
+    const int N = d.n;
+    int r[3] = { d.r[0], d.r[1], d.r[2] };
+    if (inv) { if (d.np == 3) std::swap(r[0], r[2]); else std::swap(r[0], r[1]); }
+    const int RF = r[0], RM = d.np == 3 ? r[1] : 1, RL = d.np == 3 ? r[2] : r[1];
+    const double sgn = inv ? 2.0 * M_PI : -2.0 * M_PI;
+    auto w = [&](long num, long den) { const double a = sgn * (double)(num % den) / (double)den; return make_float2((float)cos(a), (float)sin(a)); };
+    std::vector<float2> t;
+    if (d.np == 2) {
+        t.resize((size_t)RL * RF);
+        for (int q = 0; q < RL; ++q) for (int k = 0; k < RF; ++k) t[(size_t)q * RF + k] = w((long)q * k, N);
+    } else {
+        const int NS = RF * RM;
+        t.resize((size_t)RM * RF + (size_t)RL * NS);
+        for (int q = 0; q < RM; ++q) for (int k = 0; k < RF; ++k) t[(size_t)q * RF + k] = w((long)q * k, NS);
+        for (int q = 0; q < RL; ++q) for (int k = 0; k < NS; ++k) t[(size_t)RM * RF + (size_t)q * NS + k] = w((long)q * k, N);
+    }
+    return t;
+}
+
+int upload_table(nik_ctx* c, const std::vector<float2>& h, float2** d) {
+    HIP_TRY(c, hipMalloc(d, sizeof(float2) * h.size()));
+    HIP_TRY(c, hipMemcpy(*d, h.data(), sizeof(float2) * h.size(), hipMemcpyHostToDevice));
+    return NIK_OK;
+}
+
 int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     f.g.rows = rows; f.g.cols = cols; f.g.hr = rows / 2 + 1;
     f.real_elems = (size_t)rows * cols; f.spec_elems = (size_t)f.g.hr * cols;
     const int h = rows / 2;
-    auto th = twiddles(h, h), tf = twiddles(rows, h), tc = twiddles(cols, cols);
-    HIP_TRY(c, hipMalloc(&f.d_tw_half, sizeof(float2) * h));
-    HIP_TRY(c, hipMalloc(&f.d_tw_full, sizeof(float2) * h));
-    HIP_TRY(c, hipMalloc(&f.d_tw_cols, sizeof(float2) * cols));
-    HIP_TRY(c, hipMemcpy(f.d_tw_half, th.data(), sizeof(float2) * h, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(f.d_tw_full, tf.data(), sizeof(float2) * h, hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(f.d_tw_cols, tc.data(), sizeof(float2) * cols, hipMemcpyHostToDevice));
-    f.t.tw_half = f.d_tw_half; f.t.tw_full = f.d_tw_full; f.t.tw_cols = f.d_tw_cols;
+    const PlanDesc ph = plan_desc(h), pc = plan_desc(cols);
+    int rc;
+    if ((rc = upload_table(c, plan_table(ph, false), &f.d_tw[0])) || (rc = upload_table(c, plan_table(ph, true), &f.d_tw[1])) ||
+        (rc = upload_table(c, twiddles(rows, h), &f.d_tw[2])) ||
+        (rc = upload_table(c, plan_table(pc, false), &f.d_tw[3])) || (rc = upload_table(c, plan_table(pc, true), &f.d_tw[4]))) return rc;
+    f.t.half_f = f.d_tw[0]; f.t.half_i = f.d_tw[1]; f.t.tw_full = f.d_tw[2]; f.t.cols_f = f.d_tw[3]; f.t.cols_i = f.d_tw[4];
     return NIK_OK;
 }
 
@@ -430,7 +455,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
 void nik_destroy(nik_ctx* c) {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (Family* f : { &c->img, &c->pol }) { (void)hipFree(f->d_tw_half); (void)hipFree(f->d_tw_full); (void)hipFree(f->d_tw_cols); }
+    for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
     (void)hipFree(c->tmpA); (void)hipFree(c->kbuf); (void)hipFree(c->gbuf); (void)hipFree(c->pplane); (void)hipFree(c->partials);
     (void)hipFree(c->maxbuf); (void)hipFree(c->energy); (void)hipFree(c->rot_res); (void)hipFree(c->trans_res); (void)hipFree(c->d_idx);
@@ -651,6 +676,8 @@ int nik_profile_read(nik_ctx* c, nik_stage_stat* out, int cap, int* n) {
 }
 
 // ---- debug taps ---------------------------------------------------------------------------------
+
+int nik_dbg_set_ablate(int flags) { set_ablate(flags); return NIK_OK; }
 
 int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     if (!c || !x || !xf_out) return NIK_ERR_INVALID_ARG;

@@ -1,0 +1,207 @@
+// kcc_fft2.h -- register-resident FFT engine for gfx950.
+//
+// A line of N complex points is transformed by 2 or 3 large-radix Stockham passes.  One thread owns one
+// butterfly of a pass: its R points live in VGPRs, the radix-R DFT is a fully unrolled Cooley-Tukey
+// recursion over base radices {2,3,4,5,7,8} with compile-time twiddle constants, and passes exchange
+// data through one padded LDS buffer per line (write, one barrier, read).  The inverse transform uses the
+// radices in reverse order, so the register layout after the last pass of one direction IS the first-pass
+// input layout of the other direction: fused inverse -> pointwise -> forward (and forward -> pointwise ->
+// inverse) stages never leave registers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "kcc_consts.h"
+#include "kcc_fft.h"   // base radices Radix<2,3,4,5,7,8>, complex helpers
+
+namespace kcc {
+
+__host__ __device__ constexpr bool is_base_radix(int r) { return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8; }
+__host__ __device__ constexpr int first_factor(int r) {
+    return is_base_radix(r) ? r : (r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : 7);
+}
+// register index holding output k of dft_run<R>
+template <int R> __host__ __device__ constexpr int dft_pos(int k) {
+    return is_base_radix(R) ? k : (R / first_factor(R)) * (k % first_factor(R)) + k / first_factor(R);
+}
+
+// In-register DFT of R points (R = product of base radices).  Output k ends up in v[dft_pos<R>(k)].
+template <int R, bool INV>
+__device__ __forceinline__ void dft_run(float2 (&v)[R]) {
+    if constexpr (is_base_radix(R)) {
+        Radix<R, INV>::run(v);
+    } else {
+        constexpr int A = first_factor(R), B = R / A;
+        // n = B*n1 + n2, k = k1 + A*k2:  DFT_A over n1, twiddle W_R^(n2*k1), DFT_B over n2
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) {
+            float2 t[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) t[n1] = v[B * n1 + n2];
+            dft_run<A, INV>(t);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) v[B * k1 + n2] = t[dft_pos<A>(k1)];
+        }
+#pragma unroll
+        for (int k1 = 1; k1 < A; ++k1) {
+#pragma unroll
+            for (int n2 = 1; n2 < B; ++n2) {
+                const int idx = (n2 * k1) % R;
+                float2& x = v[B * k1 + n2];
+                if ((4 * idx) % R == 0) {                     // W = (-i)^(4 idx / R): free
+                    const int e = ((4 * idx) / R) & 3;
+                    const int ee = INV ? ((4 - e) & 3) : e;
+                    if (ee == 1) x = make_float2(x.y, -x.x);
+                    else if (ee == 2) x = make_float2(-x.x, -x.y);
+                    else if (ee == 3) x = make_float2(-x.y, x.x);
+                } else {
+                    const float2 w = make_float2(Wc<R>::c[idx], Wc<R>::s[idx]);
+                    x = INV ? cmulc(x, w) : cmul(x, w);
+                }
+            }
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            float2 u[B];
+#pragma unroll
+            for (int n2 = 0; n2 < B; ++n2) u[n2] = v[B * k1 + n2];
+            dft_run<B, INV>(u);
+#pragma unroll
+            for (int k2 = 0; k2 < B; ++k2) v[B * k1 + k2] = u[dft_pos<B>(k2)];
+        }
+    }
+}
+
+__host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// FFT plan: N = R1*R2 (*R3).  Forward applies R1, R2, R3; inverse applies them reversed.
+template <int N_, int R1_, int R2_, int R3_ = 1>
+struct Plan {
+    static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_;
+    static constexpr int NP = R3_ > 1 ? 3 : 2;
+    static_assert(R1_ * R2_ * R3_ == N_, "plan radices must multiply to N");
+    // threads per line = most butterflies in any pass
+    static constexpr int T = cmax(cmax(N_ / R1_, N_ / R2_), R3_ > 1 ? N_ / R3_ : 0);
+    template <bool INV> static constexpr int RF() { return INV ? (NP == 3 ? R3_ : R2_) : R1_; }   // first radix
+    template <bool INV> static constexpr int RM() { return R2_; }                                  // middle (NP==3)
+    template <bool INV> static constexpr int RL() { return INV ? R1_ : (NP == 3 ? R3_ : R2_); }   // last radix
+    // exchange buffer: index i is stored at i + i/PAD (PAD = first radix of the direction): pass-1 writes
+    // (stride RF) become stride RF+1 and the later strided-run writes land on distinct banks.
+    static constexpr int RMIN = (R3_ > 1 && R3_ < (R1_ < R2_ ? R1_ : R2_)) ? R3_ : (R1_ < R2_ ? R1_ : R2_);
+    static constexpr int EXT = N_ + N_ / RMIN + 2;
+};
+
+// instantiated lengths
+template <int N> struct PlanFor;
+template <> struct PlanFor<30> : Plan<30, 5, 6> {};
+template <> struct PlanFor<60> : Plan<60, 6, 10> {};
+template <> struct PlanFor<120> : Plan<120, 10, 12> {};
+template <> struct PlanFor<240> : Plan<240, 15, 16> {};
+template <> struct PlanFor<360> : Plan<360, 18, 20> {};
+template <> struct PlanFor<80> : Plan<80, 8, 10> {};
+template <> struct PlanFor<160> : Plan<160, 10, 16> {};
+template <> struct PlanFor<320> : Plan<320, 16, 20> {};
+template <> struct PlanFor<480> : Plan<480, 8, 6, 10> {};
+template <> struct PlanFor<640> : Plan<640, 8, 8, 10> {};
+template <> struct PlanFor<1280> : Plan<1280, 8, 10, 16> {};
+
+// Twiddle table layout (built on the host, see kcc_api.hip build_plan_tables):
+//   2 passes, direction d:  tw[q*RF + k] = W_N^(+-q*k),            q < RL, k < RF
+//   3 passes, direction d:  tw[q*RF + k] = W_(RF*RM)^(+-q*k),      q < RM, k < RF          (pass 2)
+//                           tw[OFF3 + q*(RF*RM) + k] = W_N^(+-q*k), q < RL, k < RF*RM      (pass 3)
+//   with OFF3 = RM*RF.  Forward tables use the minus sign; inverse tables the plus sign (so the kernels
+//   always multiply, never conjugate).
+template <class P, bool INV> struct Dir {
+    static constexpr int N = P::N;
+    static constexpr int RF = P::template RF<INV>(), RM = P::template RM<INV>(), RL = P::template RL<INV>();
+    static constexpr int MF = N / RF, ML = N / RL;           // butterflies (= active threads) in first / last pass
+    static constexpr int MM = P::NP == 3 ? N / RM : 0;
+    static constexpr int PAD = RF;
+    static constexpr int OFF3 = RM * RF;
+    // strided reads i = j + q*M map to phys(j) + q*(M + M/PAD) when PAD divides M (true for every plan here)
+    static_assert(ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0), "pad must divide the pass strides");
+    static constexpr int SL = ML + ML / PAD;                 // phys stride of last-pass reads
+    static constexpr int SM = P::NP == 3 ? MM + MM / PAD : 0;
+    __device__ static __forceinline__ unsigned phys(unsigned i) { return i + i / (unsigned)PAD; }
+};
+
+// Run all passes of one direction on NV independent lines owned by this thread (same j, different data),
+// each with its own exchange buffer ex[v] (LDS, >= P::EXT float2).
+//   in : vin[v][q]  = x[j + q*MF]          (valid for j < MF)
+//   out: vout[v][q] = X[j + q*ML]          (valid for j < ML), natural order
+// All threads of the workgroup must call this (it contains barriers); the caller must place a barrier
+// between two chains that share an exchange buffer.
+template <class P, bool INV, int NV, int RFV, int RLV>
+__device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)[NV][RLV],
+                                          unsigned j, float2* const (&ex)[NV], const float2* __restrict__ tw) {
+    using D = Dir<P, INV>;
+    constexpr int RF = D::RF, RL = D::RL, RM = D::RM;
+    static_assert(RFV == RF && RLV == RL, "register arrays must match the plan's first / last radix");
+    // ---- pass 1: radix RF, Ns = 1 (no twiddles); output q of butterfly j goes to phys(j*RF + q) = j*(RF+1) + q
+    if (j < (unsigned)D::MF) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            dft_run<RF, INV>(vin[v]);
+            float2* w = ex[v] + j * (RF + 1);
+#pragma unroll
+            for (int q = 0; q < RF; ++q) w[q] = vin[v][dft_pos<RF>(q)];
+        }
+    }
+    if constexpr (P::NP == 3) {
+        // ---- pass 2: radix RM, Ns = RF
+        constexpr int MM = D::MM;
+        float2 vm[NV][RM];
+        float2 w2[RM];
+        const unsigned k = j % (unsigned)RF, jb = j / (unsigned)RF;
+        const bool act = j < (unsigned)MM;
+        if (act) {
+#pragma unroll
+            for (int q = 1; q < RM; ++q) w2[q] = tw[q * RF + k];
+        }
+        __syncthreads();
+        if (act) {
+            const unsigned pj = D::phys(j);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int q = 0; q < RM; ++q) vm[v][q] = ex[v][pj + q * D::SM];
+        }
+        __syncthreads();
+        if (act) {
+            // phys(jb*RF*RM + k + q*RF) = jb*(RF*RM + RM) + k + q*(RF+1)
+            const unsigned wb = jb * (RF * RM + RM) + k;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+#pragma unroll
+                for (int q = 1; q < RM; ++q) vm[v][q] = cmul(vm[v][q], w2[q]);
+                dft_run<RM, INV>(vm[v]);
+#pragma unroll
+                for (int q = 0; q < RM; ++q) ex[v][wb + q * (RF + 1)] = vm[v][dft_pos<RM>(q)];
+            }
+        }
+    }
+    // ---- last pass: radix RL, Ns = N/RL = ML, k = j
+    float2 wl[RL];
+    const bool actl = j < (unsigned)D::ML;
+    if (actl) {
+        const float2* t = tw + (P::NP == 3 ? D::OFF3 : 0) + j;
+#pragma unroll
+        for (int q = 1; q < RL; ++q) wl[q] = t[q * D::ML];
+    }
+    __syncthreads();
+    if (actl) {
+        const unsigned pj = D::phys(j);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            float2 t[RL];
+#pragma unroll
+            for (int q = 0; q < RL; ++q) t[q] = ex[v][pj + q * D::SL];
+#pragma unroll
+            for (int q = 1; q < RL; ++q) t[q] = cmul(t[q], wl[q]);
+            dft_run<RL, INV>(t);
+#pragma unroll
+            for (int q = 0; q < RL; ++q) vout[v][q] = t[dft_pos<RL>(q)];
+        }
+    }
+}
+
+}  // namespace kcc

@@ -40,14 +40,22 @@ struct PlaneGeom {
     int hr;              // rows/2+1
 };
 
+void set_ablate(int flags);      // debug: 1 = no global loads, 2 = no global stores, 4 = no FFT chains (B-type kernels)
 bool fft_half_supported(int h);   // rows/2 instantiated?
 bool fft_line_supported(int n);   // cols instantiated?
 
+// pass-twiddle tables of one FFT plan, one per direction (layout: kcc_fft2.h "Twiddle table layout")
 struct Tables {
-    const float2* tw_half;   // W_h,  h = rows/2   (h entries)
-    const float2* tw_full;   // W_{2h} first h entries (r2c / c2r post-twiddles)
-    const float2* tw_cols;   // W_cols (cols entries)
+    const float2* half_f;    // plan of length rows/2, forward
+    const float2* half_i;    // plan of length rows/2, inverse
+    const float2* tw_full;   // W_{2h}^k, k < h: r2c / c2r split twiddles
+    const float2* cols_f;    // plan of length cols, forward
+    const float2* cols_i;    // plan of length cols, inverse
 };
+
+// radices of the instantiated plan for length n (np = 0 if n is not instantiated)
+struct PlanDesc { int n, np, r[3]; };
+PlanDesc plan_desc(int n);
 
 // ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,

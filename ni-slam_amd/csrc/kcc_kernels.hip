@@ -1,19 +1,20 @@
-// kcc_kernels.hip -- gfx950 kernels of the KCC front end.
+// kcc_kernels.hip -- gfx950 kernels of the KCC front end (register-resident FFT engine, kcc_fft2.h).
 //
 // Two kernel families implement every 2-D real FFT of the path (reference correlation_flow.cc:53-77):
-//   A-type: LX lines along the halved axis (rows) per workgroup; real<->half-complex via one complex
-//           FFT of length rows/2; the spectrum side is accessed transposed in 128-byte segments.
-//   B-type: LK contiguous spectrum lines (length cols) per workgroup.
+//   A-type: 16 lines along the halved axis (rows) per workgroup; real<->half-complex via one complex FFT
+//           of length rows/2; the spectrum side is accessed transposed in 128-byte segments, with the
+//           r2c split / c2r merge fused into that transposed access.
+//   B-type: LK contiguous spectrum lines (length cols) per workgroup, loaded straight into registers.
 // Spectra are stored k-major ([rows/2+1][cols], cols contiguous) so the B pass is fully coalesced.
-// All pointwise work of the path (|F|, X conj Z, kernel function, ridge solve, max, arg-max, PSR
-// moments, polar / rotation gathers) is fused into the load or store side of these passes.
+// All pointwise work of the path (|F|, X conj Z, kernel function, ridge solve, max, arg-max, PSR moments,
+// polar / rotation gathers) is fused into these passes and runs on registers.
 #include "kcc_kernels.h"
-#include "kcc_fft.h"
+#include "kcc_fft2.h"
 
 namespace kcc {
 
 // ------------------------------------------------------------------------------------------------
-// instantiated FFT lengths
+// instantiated FFT lengths (plans: kcc_fft2.h PlanFor<>)
 // ------------------------------------------------------------------------------------------------
 #define KCC_HALF_LIST(X) X(30) X(60) X(120) X(240) X(360)
 #define KCC_LINE_LIST(X) X(80) X(160) X(320) X(480) X(640) X(1280)
@@ -30,10 +31,19 @@ bool fft_line_supported(int n_) {
 #undef X
     return false;
 }
+PlanDesc plan_desc(int n_) {
+    PlanDesc d{ n_, 0, { 1, 1, 1 } };
+#define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; }
+    KCC_HALF_LIST(X)
+    KCC_LINE_LIST(X)
+#undef X
+    return d;
+}
+
+int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT
+void set_ablate(int f) { g_ablate = f; }
 
 constexpr int A_LX = 16;     // lines per A-type workgroup (16 float2 = one 128-B segment per spectrum row)
-constexpr int A_NT = 256;
-constexpr int B_NT = 256;
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -71,20 +81,37 @@ __device__ __forceinline__ int affine_base(double m1, int r, double m2) {
     return __double2int_rn(u * 1024.0);
 }
 
-// (xz + offset)^power as Eigen's Array::pow(int) does it: double pow, rounded to float.
+// (xz + offset)^power as Eigen's Array::pow(int) does it: double pow, rounded to float.  The general-power
+// path is kept out of line (it is ~100 instructions of libm pow per element).
+__device__ __noinline__ float pow_generic(float b, int p) { return (float)pow((double)b, (double)p); }
+enum { KT_POLY3 = 0, KT_POLYN = 1, KT_GAUSS = 2 };
+template <int KT>
 __device__ __forceinline__ float kernel_value(const KernelFn& fn, float xz, float gauss_bias, float gauss_scale) {
-    if (fn.type == 0) {
+    if (KT == KT_POLY3) {
         const double b = (double)(xz + fn.offset);
-        double r;
-        if (fn.power == 3) r = b * b * b;
-        else if (fn.power == 2) r = b * b;
-        else if (fn.power == 1) r = b;
-        else r = pow(b, (double)fn.power);
-        return (float)r;
+        return (float)(b * b * b);
+    } else if (KT == KT_POLYN) {
+        return pow_generic(xz + fn.offset, fn.power);
+    } else {
+        // gaussian: exp(-1/sigma^2 * (xx + zz - 2 xz)/N)   (correlation_flow.cc:189-190)
+        return __expf((gauss_bias - 2.f * xz) * gauss_scale);
     }
-    // gaussian: exp(-1/sigma^2 * (xx + zz - 2 xz)/N)   (correlation_flow.cc:189-190)
-    const float xxzz = (gauss_bias - 2.f * xz) * gauss_scale;       // gauss_scale = 1/N (as division below)
-    return __expf(xxzz);
+}
+
+// Workgroups of one item share its source plane (gathers): put them on the same XCD (the dispatcher places
+// linear block b on XCD b % 8), so the plane is fetched into one L2 instead of eight.  Speed only.
+__device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& item) {
+    const int L = blockIdx.x;
+    const int full_items = (n_items / 8) * 8;
+    if (L < full_items * nbx) {
+        const int xcd = L & 7, q = L >> 3;
+        item = (q / nbx) * 8 + xcd;
+        bx = q % nbx;
+    } else {
+        const int r = L - full_items * nbx;
+        item = full_items + r / nbx;
+        bx = r % nbx;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -117,18 +144,15 @@ void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
 enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };
-enum { EPI_REAL = 0, EPI_KERNEL_FWD = 1, EPI_ARGMAX = 2 };
+enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4 };
+__host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
 struct AArgs {
-    // geometry of the transformed plane
-    int rows, cols, hr;
-    const float2* tw_half;
-    const float2* tw_full;
+    int rows, cols, hr, n_items;
+    const float2* tw_f; const float2* tw_i; const float2* tw_full;
     // forward source
     const float* src; size_t src_stride; const int* src_idx;
-    // rotation source
     const RotEntry* rot_tab; const int* rot_index;
-    // polar source (src = p planes, H x W)
     int H, W; const uint32_t* polar_tab;
     // spectrum side
     float2* spec; size_t spec_stride; size_t plane_stride;
@@ -138,91 +162,16 @@ struct AArgs {
     KernelFn fn; unsigned* maxbuf; const float* energy;
 };
 
-// LDS layout of one A workgroup: LX lines x (h+1) float2 (pitch odd -> conflict-free transposes), + W_h table
-template <int HH> struct ALds {
-    static constexpr int PITCH = HH + 1;
-    static constexpr int DATA = A_LX * PITCH;
-    static constexpr size_t BYTES = (size_t)(DATA + HH) * sizeof(float2);
+template <int HH> struct ACfg {
+    using P = PlanFor<HH>;
+    static constexpr int T = P::T;                       // threads per line
+    static constexpr int NT = A_LX * T;
+    // exchange pitch: >= EXT and == T (mod 32) so the lines sharing a wave-instruction use disjoint banks
+    static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
+    static constexpr int NPITCH = HH + 1;                // natural-order pitch: odd -> conflict-free transposes
+    static constexpr int LDS_ELEMS = A_LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
+    static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
 };
-
-template <int HH>
-__device__ __forceinline__ void a_load_tw(float2* tw_lds, const float2* __restrict__ tw_half, int tid) {
-    for (int i = tid; i < HH; i += A_NT) tw_lds[i] = tw_half[i];
-}
-
-// spectrum tile [k][x0..x0+LX) (global, k-major)  ->  lds[xx][k]
-template <int HH>
-__device__ __forceinline__ void a_load_spec(float2* lds, const float2* __restrict__ spec, int cols, int x0, int tid) {
-    constexpr int PITCH = ALds<HH>::PITCH;
-    for (int idx = tid; idx < (HH + 1) * A_LX; idx += A_NT) {
-        const int xx = idx % A_LX, k = idx / A_LX;
-        lds[xx * PITCH + k] = spec[(size_t)k * cols + x0 + xx];
-    }
-}
-template <int HH>
-__device__ __forceinline__ void a_store_spec(const float2* lds, float2* __restrict__ spec, int cols, int x0, int tid) {
-    constexpr int PITCH = ALds<HH>::PITCH;
-    for (int idx = tid; idx < (HH + 1) * A_LX; idx += A_NT) {
-        const int xx = idx % A_LX, k = idx / A_LX;
-        spec[(size_t)k * cols + x0 + xx] = lds[xx * PITCH + k];
-    }
-}
-
-// Z (FFT of the packed line) -> X[0..h] in place  (r2c split)
-template <int HH>
-__device__ __forceinline__ void a_r2c_post(float2* lds, const float2* __restrict__ tw_full, int tid) {
-    constexpr int PITCH = ALds<HH>::PITCH;
-    constexpr int NP = HH / 2 + 1;
-    for (int idx = tid; idx < A_LX * NP; idx += A_NT) {
-        const int line = idx / NP, k = idx - line * NP;
-        float2* L = lds + line * PITCH;
-        if (k == 0) {
-            const float2 z = L[0];
-            L[0] = make_float2(z.x + z.y, 0.f);
-            L[HH] = make_float2(z.x - z.y, 0.f);
-        } else {
-            const float2 a = L[k], b = cconj(L[HH - k]);
-            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-            const float2 o = make_float2(d.y, -d.x);            // -i d
-            const float2 t = cmul(tw_full[k], o);
-            L[k] = cadd(e, t);
-            if (2 * k != HH) L[HH - k] = cconj(csub(e, t));
-        }
-    }
-}
-// X[0..h] -> Z' (input of the inverse packed FFT), in place  (c2r merge; imag of X[0], X[h] ignored like FFTW)
-template <int HH>
-__device__ __forceinline__ void a_c2r_pre(float2* lds, const float2* __restrict__ tw_full, int tid) {
-    constexpr int PITCH = ALds<HH>::PITCH;
-    constexpr int NP = HH / 2 + 1;
-    for (int idx = tid; idx < A_LX * NP; idx += A_NT) {
-        const int line = idx / NP, k = idx - line * NP;
-        float2* L = lds + line * PITCH;
-        if (k == 0) {
-            const float x0 = L[0].x, xh = L[HH].x;
-            L[0] = make_float2(x0 + xh, x0 - xh);
-        } else {
-            const float2 a = L[k], b = cconj(L[HH - k]);
-            const float2 sm = cadd(a, b), d = csub(a, b);
-            const float2 u = cmulc(d, tw_full[k]);               // conj(w^k) * d
-            const float2 iu = make_float2(-u.y, u.x);
-            L[k] = cadd(sm, iu);
-            if (2 * k != HH) L[HH - k] = cconj(csub(sm, iu));
-        }
-    }
-}
-
-// value of fftshift(RemoveZeroComponent(p)) at shifted coordinates (y, x), zero outside
-// (correlation_flow.cc:79-87,93-94; circ_shift.h:131-154,238-244)
-__device__ __forceinline__ float shifted_hp(const float* __restrict__ p, int H, int W, int y, int x) {
-    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return 0.f;
-    int r = y - H / 2; if (r < 0) r += H;
-    int c = x - W / 2; if (c < 0) c += W;
-    if (c == 0) return (p[(size_t)1 * H + r] + p[(size_t)(W - 1) * H + r]) * 0.5f;
-    if (r == 0) return (p[(size_t)c * H + 1] + p[(size_t)c * H + H - 1]) * 0.5f;
-    return p[(size_t)c * H + r];
-}
 
 // RotateArray (utils.cc:154-161): cv::warpAffine(INTER_LINEAR, BORDER_WRAP) with the inverse matrix of the
 // candidate angle; fixed-point coordinates exactly as OpenCV's WarpAffineInvoker.  dst pixel (r, c).
@@ -239,6 +188,16 @@ __device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H
     return bilerp(img[(size_t)xa * H + ya], img[(size_t)xb * H + ya],
                   img[(size_t)xa * H + yb], img[(size_t)xb * H + yb], X & 31, Y & 31);
 }
+// value of fftshift(RemoveZeroComponent(p)) at shifted coordinates (y, x), zero outside
+// (correlation_flow.cc:79-87,93-94; circ_shift.h:131-154,238-244)
+__device__ __forceinline__ float shifted_hp(const float* __restrict__ p, int H, int W, int y, int x) {
+    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return 0.f;
+    int r = y - H / 2; if (r < 0) r += H;
+    int c = x - W / 2; if (c < 0) c += W;
+    if (c == 0) return (p[(size_t)1 * H + r] + p[(size_t)(W - 1) * H + r]) * 0.5f;
+    if (r == 0) return (p[(size_t)c * H + 1] + p[(size_t)c * H + H - 1]) * 0.5f;
+    return p[(size_t)c * H + r];
+}
 // polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven remap sample
 __device__ __forceinline__ float polar_sample(const float* __restrict__ p, int H, int W, uint32_t t) {
     const int sx = t & 0x7FF, sy = (t >> 11) & 0x7FF, fx = (t >> 22) & 31, fy = t >> 27;
@@ -246,115 +205,217 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ p, int H
                   shifted_hp(p, H, W, sy + 1, sx), shifted_hp(p, H, W, sy + 1, sx + 1), fx, fy);
 }
 
-template <int HH, int SRC>
-__global__ __launch_bounds__(A_NT) void kA_fwd(AArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PITCH = ALds<HH>::PITCH;
-    float2* lds = reinterpret_cast<float2*>(smem);
-    float2* tw = lds + ALds<HH>::DATA;
-    const int tid = threadIdx.x, item = blockIdx.y, x0 = blockIdx.x * A_LX;
-    a_load_tw<HH>(tw, a.tw_half, tid);
-
-    if (SRC == SRC_PLANE) {
-        const int pl = a.src_idx ? a.src_idx[item] : item;
-        const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)x0 * a.rows);
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            lds[line * PITCH + m] = src[(size_t)line * HH + m];
-        }
-    } else if (SRC == SRC_ROT) {
-        const int H = a.rows, W = a.cols;
-        const float* img = a.src + (size_t)a.src_idx[item] * a.src_stride;
-        const RotEntry R = a.rot_tab[a.rot_index[item]];
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            const int c = x0 + line;
-            lds[line * PITCH + m] = make_float2(rot_sample(img, H, W, R, 2 * m, c), rot_sample(img, H, W, R, 2 * m + 1, c));
-        }
-    } else {
-        const int PD = a.rows;
-        const float* p = a.src + (size_t)item * a.src_stride;
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            const uint32_t* tab = a.polar_tab + (size_t)(x0 + line) * PD + 2 * m;
-            lds[line * PITCH + m] = make_float2(polar_sample(p, a.H, a.W, tab[0]), polar_sample(p, a.H, a.W, tab[1]));
+// natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
+// All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
+template <int HH>
+__device__ __forceinline__ void a_post_store(const float2* nat, const float2* __restrict__ tw_full,
+                                             float2* __restrict__ spec, int cols, int x0, int tid) {
+    constexpr int NPITCH = ACfg<HH>::NPITCH, NT = ACfg<HH>::NT, NP = HH / 2 + 1;
+    constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
+    float2 va[ITERS], vb[ITERS], w[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < TOT) {
+            const int xx = idx % A_LX, k = idx / A_LX;
+            va[it] = nat[xx * NPITCH + k]; vb[it] = nat[xx * NPITCH + (k ? HH - k : 0)]; w[it] = tw_full[k];
         }
     }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < TOT) {
+            const int xx = idx % A_LX, k = idx / A_LX;
+            float2* g = spec + x0 + xx;
+            if (k == 0) {
+                const float2 z = va[it];
+                g[0] = make_float2(z.x + z.y, 0.f);
+                g[(size_t)HH * cols] = make_float2(z.x - z.y, 0.f);
+            } else {
+                const float2 a = va[it], b = cconj(vb[it]);
+                const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
+                const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
+                const float2 t = cmul(w[it], make_float2(d.y, -d.x));       // w^k * (-i d)
+                g[(size_t)k * cols] = cadd(e, t);
+                if (2 * k != HH) g[(size_t)(HH - k) * cols] = cconj(csub(e, t));
+            }
+        }
+    }
+}
+// transposed global load (k-major spectrum) -> c2r merge -> natural-order input of the packed inverse FFT in LDS.
+// All global loads of a thread are issued before the arithmetic.
+template <int HH>
+__device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict__ tw_full,
+                                           const float2* __restrict__ spec, int cols, int x0, int tid) {
+    constexpr int NPITCH = ACfg<HH>::NPITCH, NT = ACfg<HH>::NT, NP = HH / 2 + 1;
+    constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
+    float2 va[ITERS], vb[ITERS], w[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < TOT) {
+            const int xx = idx % A_LX, k = idx / A_LX;
+            const float2* g = spec + x0 + xx;
+            va[it] = g[(size_t)k * cols]; vb[it] = g[(size_t)(HH - k) * cols]; w[it] = tw_full[k];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int idx = tid + it * NT;
+        if (idx < TOT) {
+            const int xx = idx % A_LX, k = idx / A_LX;
+            float2* L = nat + xx * NPITCH;
+            if (k == 0) {
+                const float xa = va[it].x, xh = vb[it].x;                    // imag of DC / Nyquist ignored (FFTW c2r)
+                L[0] = make_float2(xa + xh, xa - xh);
+            } else {
+                const float2 a = va[it], b = cconj(vb[it]);
+                const float2 sm = cadd(a, b), d = csub(a, b);
+                const float2 u = cmulc(d, w[it]);                             // conj(w^k) * d
+                const float2 iu = make_float2(-u.y, u.x);
+                L[k] = cadd(sm, iu);
+                if (2 * k != HH) L[HH - k] = cconj(csub(sm, iu));
+            }
+        }
+    }
+}
+
+template <int HH, int SRC>
+__global__ __launch_bounds__(ACfg<HH>::NT) void kA_fwd(AArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = ACfg<HH>; using P = typename C::P; using D = Dir<P, false>;
+    float2* lds = reinterpret_cast<float2*>(smem);
+    const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
+    int bx, item;
+    xcd_coords(a.cols / A_LX, a.n_items, bx, item);
+    const int x0 = bx * A_LX;
+
+    float2 vin[1][D::RF], vout[1][D::RL];
+    if (j < D::MF) {
+        if (SRC == SRC_PLANE) {
+            const int pl = a.src_idx ? a.src_idx[item] : item;
+            const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.rows);
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
+        } else if (SRC == SRC_ROT) {
+            const float* img = a.src + (size_t)a.src_idx[item] * a.src_stride;
+            const RotEntry R = a.rot_tab[a.rot_index[item]];
+            const int c = x0 + line;
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) {
+                const int m = j + q * D::MF;
+                vin[0][q] = make_float2(rot_sample(img, a.rows, a.cols, R, 2 * m, c), rot_sample(img, a.rows, a.cols, R, 2 * m + 1, c));
+            }
+        } else {
+            const float* p = a.src + (size_t)item * a.src_stride;
+            const uint32_t* tab = a.polar_tab + (size_t)(x0 + line) * a.rows;
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) {
+                const int m = j + q * D::MF;
+                const uint2 t = *reinterpret_cast<const uint2*>(tab + 2 * m);
+                vin[0][q] = make_float2(polar_sample(p, a.H, a.W, t.x), polar_sample(p, a.H, a.W, t.y));
+            }
+        }
+    }
+    float2* const ex[1] = { lds + line * C::EPITCH };
+    fft_chain<P, false, 1>(vin, vout, j, ex, a.tw_f);
+    __syncthreads();                                         // exchange buffer fully consumed
+    if (j < D::ML) {
+#pragma unroll
+        for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
+    }
     __syncthreads();
-    line_fft<HH, A_LX, A_NT, PITCH, false>(lds, tw, tid);
-    a_r2c_post<HH>(lds, a.tw_full, tid);
-    __syncthreads();
-    a_store_spec<HH>(lds, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+    a_post_store<HH>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
 }
 
 template <int HH, int EPI>
-__global__ __launch_bounds__(A_NT) void kA_inv(AArgs a) {
+__global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int PITCH = ALds<HH>::PITCH;
+    using C = ACfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
+    constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
-    float2* tw = lds + ALds<HH>::DATA;
-    __shared__ float red_f[A_NT / 64];
-    __shared__ int red_i[A_NT / 64];
-    __shared__ double red_d[2][A_NT / 64];
-    const int tid = threadIdx.x, item = blockIdx.y, x0 = blockIdx.x * A_LX;
-    const int plane = (EPI == EPI_KERNEL_FWD) ? blockIdx.z : 0;
+    __shared__ float red_f[NW];
+    __shared__ int red_i[NW];
+    __shared__ double red_d[2][NW];
+    const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
+    const int nbx = a.cols / A_LX;
+    int bx, item2;
+    constexpr bool KFWD = epi_is_kfwd(EPI);
+    constexpr int KT = EPI == EPI_KFWD_POLY3 ? KT_POLY3 : (EPI == EPI_KFWD_POLYN ? KT_POLYN : KT_GAUSS);
+    xcd_coords(nbx, a.n_items * (KFWD ? 2 : 1), bx, item2);
+    const int item = KFWD ? item2 >> 1 : item2;
+    const int plane = KFWD ? item2 & 1 : 0;
+    const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
-    a_load_tw<HH>(tw, a.tw_half, tid);
-    a_load_spec<HH>(lds, spec, a.cols, x0, tid);
+
+    a_load_pre<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
     __syncthreads();
-    a_c2r_pre<HH>(lds, a.tw_full, tid);
-    __syncthreads();
-    line_fft<HH, A_LX, A_NT, PITCH, true>(lds, tw, tid);
-    const float size = (float)((long)a.rows * a.cols);           // IFFT: x / x.size()  (correlation_flow.cc:76)
+    float2 vin[1][DI::RF], vout[1][DI::RL];
+    if (j < DI::MF) {
+#pragma unroll
+        for (int q = 0; q < DI::RF; ++q) vin[0][q] = lds[line * C::NPITCH + j + q * DI::MF];
+    }
+    __syncthreads();                                         // natural buffer consumed before the exchange overwrites it
+    float2* const ex[1] = { lds + line * C::EPITCH };
+    fft_chain<P, true, 1>(vin, vout, j, ex, a.tw_i);
+    const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
+    const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
 
     if (EPI == EPI_REAL) {
-        float2* dst = reinterpret_cast<float2*>(a.real_out + (size_t)item * a.real_stride + (size_t)x0 * a.rows);
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            const float2 z = lds[line * PITCH + m];
-            dst[(size_t)line * HH + m] = make_float2((z.x / size), (z.y / size));
+        if (j < DI::ML) {
+            float2* dst = reinterpret_cast<float2*>(a.real_out + (size_t)item * a.real_stride + (size_t)(x0 + line) * a.rows);
+#pragma unroll
+            for (int q = 0; q < DI::RL; ++q) dst[j + q * DI::ML] = make_float2(vout[0][q].x * rsize, vout[0][q].y * rsize);
         }
-    } else if (EPI == EPI_KERNEL_FWD) {
+    } else if (KFWD) {
+        static_assert(DI::RL == DF::RF && DI::ML == DF::MF, "inverse output layout must equal forward input layout");
         float gbias = 0.f, gscale = 0.f;
-        if (a.fn.type == 1) {
-            const float N = size;
-            const float xx = a.energy[2 * item + 0] / N, zz = a.energy[2 * item + 1] / N;
+        if (KT == KT_GAUSS) {
+            const float xx = a.energy[2 * item + 0] / size, zz = a.energy[2 * item + 1] / size;
             gbias = (plane == 0) ? (zz + zz) : (xx + zz);
-            gscale = (-1.f / (a.fn.sigma * a.fn.sigma)) / N;
+            gscale = (-1.f / (a.fn.sigma * a.fn.sigma)) / size;
         }
         float mx = 0.f;
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            const float2 z = lds[line * PITCH + m];
-            const float k0 = kernel_value(a.fn, (z.x / size), gbias, gscale);
-            const float k1 = kernel_value(a.fn, (z.y / size), gbias, gscale);
-            mx = fmaxf(mx, fmaxf(fabsf(k0), fabsf(k1)));
-            lds[line * PITCH + m] = make_float2(k0, k1);
+        if (j < DI::ML) {
+#pragma unroll
+            for (int q = 0; q < DI::RL; ++q) {
+                const float k0 = kernel_value<KT>(a.fn, vout[0][q].x * rsize, gbias, gscale);
+                const float k1 = kernel_value<KT>(a.fn, vout[0][q].y * rsize, gbias, gscale);
+                mx = fmaxf(mx, fmaxf(fabsf(k0), fabsf(k1)));
+                vout[0][q] = make_float2(k0, k1);
+            }
         }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
         if ((tid & 63) == 0) red_f[tid >> 6] = mx;
-        __syncthreads();
+        __syncthreads();                                     // also: exchange buffer consumed before the forward chain
         if (tid == 0) {
             float m2 = red_f[0];
-            for (int w = 1; w < A_NT / 64; ++w) m2 = fmaxf(m2, red_f[w]);
+            for (int w = 1; w < NW; ++w) m2 = fmaxf(m2, red_f[w]);
             atomicMax(a.maxbuf + 2 * item + plane, __float_as_uint(m2));   // non-negative floats order as uints
         }
-        line_fft<HH, A_LX, A_NT, PITCH, false>(lds, tw, tid);
-        a_r2c_post<HH>(lds, a.tw_full, tid);
+        float2 fout[1][DF::RL];
+        fft_chain<P, false, 1>(vout, fout, j, ex, a.tw_f);
         __syncthreads();
-        a_store_spec<HH>(lds, spec, a.cols, x0, tid);
+        if (j < DF::ML) {
+#pragma unroll
+            for (int q = 0; q < DF::RL; ++q) lds[line * C::NPITCH + j + q * DF::ML] = fout[0][q];
+        }
+        __syncthreads();
+        a_post_store<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
     } else {
         // arg-max (column-major first strict max, Eigen maxCoeff visitor) + moments for GetInfo
         float best = -INFINITY; int bidx = 0x7FFFFFFF;
         float s1 = 0.f, s2 = 0.f;
-        for (int idx = tid; idx < A_LX * HH; idx += A_NT) {
-            const int line = idx / HH, m = idx - line * HH;
-            const float2 z = lds[line * PITCH + m];
-            const float g0 = (z.x / size), g1 = (z.y / size);
-            const int li = (x0 + line) * a.rows + 2 * m;
-            if (g0 > best) { best = g0; bidx = li; }
-            if (g1 > best) { best = g1; bidx = li + 1; }
-            s1 += g0 + g1; s2 += g0 * g0 + g1 * g1;
+        if (j < DI::ML) {
+            const int base = (x0 + line) * a.rows;
+#pragma unroll
+            for (int q = 0; q < DI::RL; ++q) {               // increasing q -> increasing linear index
+                const float g0 = vout[0][q].x * rsize, g1 = vout[0][q].y * rsize;
+                const int li = base + 2 * (j + q * DI::ML);
+                if (g0 > best) { best = g0; bidx = li; }
+                if (g1 > best) { best = g1; bidx = li + 1; }
+                s1 += g0 + g1; s2 += g0 * g0 + g1 * g1;
+            }
         }
         double d1 = (double)s1, d2 = (double)s2;
         for (int off = 32; off >= 1; off >>= 1) {
@@ -365,30 +426,32 @@ __global__ __launch_bounds__(A_NT) void kA_inv(AArgs a) {
         if ((tid & 63) == 0) { red_f[tid >> 6] = best; red_i[tid >> 6] = bidx; red_d[0][tid >> 6] = d1; red_d[1][tid >> 6] = d2; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < A_NT / 64; ++w) {
+            for (int w = 1; w < NW; ++w) {
                 if (red_f[w] > best || (red_f[w] == best && red_i[w] < bidx)) { best = red_f[w]; bidx = red_i[w]; }
                 d1 += red_d[0][w]; d2 += red_d[1][w];
             }
             Partial p; p.sum = d1; p.sumsq = d2; p.peak = best; p.idx = bidx;
-            a.partials[(size_t)item * a.partial_stride + blockIdx.x] = p;
+            a.partials[(size_t)item * a.partial_stride + bx] = p;
         }
     }
 }
 
 int argmax_blocks(PlaneGeom g) { return g.cols / A_LX; }
 
-template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, const AArgs& a) {
-    dim3 grid(a.cols / A_LX, n_items), block(A_NT);
-    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, ALds<HH>::BYTES, s, a);
+template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
+    a.n_items = n_items;
+    dim3 grid((a.cols / A_LX) * n_items), block(ACfg<HH>::NT);
+    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, ACfg<HH>::BYTES, s, a);
 }
-template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, const AArgs& a) {
-    dim3 grid(a.cols / A_LX, n_items, nz), block(A_NT);
-    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ALds<HH>::BYTES, s, a);
+template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
+    a.n_items = n_items;
+    dim3 grid((a.cols / A_LX) * n_items * nz), block(ACfg<HH>::NT);
+    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ACfg<HH>::BYTES, s, a);
 }
 
 static AArgs base_args(PlaneGeom g, Tables t) {
     AArgs a{};
-    a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_half = t.tw_half; a.tw_full = t.tw_full;
+    a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full;
     return a;
 }
 
@@ -439,9 +502,19 @@ void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, 
                              size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy) {
     AArgs a = base_args(g, t);
     a.spec = buf; a.spec_stride = item_stride; a.plane_stride = plane_stride; a.fn = fn; a.maxbuf = maxbuf; a.energy = energy;
-#define CALL(HH) launchA_inv_t<HH, EPI_KERNEL_FWD>(s, n_items, 2, a)
-    DISPATCH_HALF(g.rows / 2, CALL)
+    if (fn.type == 1) {
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_GAUSS>(s, n_items, 2, a)
+        DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
+    } else if (fn.power == 3) {
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLY3>(s, n_items, 2, a)
+        DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
+    } else {
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLYN>(s, n_items, 2, a)
+        DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
+    }
 }
 void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                          Partial* partials, int partial_stride) {
@@ -458,8 +531,8 @@ void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, cons
 enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_INV = 4, B_INV = 5 };
 
 struct BArgs {
-    int cols, hr;
-    const float2* tw_cols;
+    int cols, hr, ablate;
+    const float2* tw_f; const float2* tw_i;
     const float2* src; size_t src_stride; const int* src_idx;     // primary input
     const float2* zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
     size_t in_plane_stride;                                       // SOLVE: plane 1 offset inside src item
@@ -470,119 +543,129 @@ struct BArgs {
 };
 
 template <int N> struct BCfg {
-    static constexpr int LK = (N <= 160) ? 8 : (N <= 640 ? 2 : 1);     // lines per set
-    static constexpr size_t BYTES = (size_t)(2 * LK * N + N) * sizeof(float2);
+    using P = PlanFor<N>;
+    static constexpr int T = P::T;
+    static constexpr int LK = (T >= 128) ? 2 : (T >= 64 ? 4 : (T >= 20 ? 8 : 16));     // lines per workgroup
+    static constexpr int NT = LK * T;
+    static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
+    static constexpr size_t BYTES = (size_t)2 * LK * EPITCH * sizeof(float2);             // two exchange buffers per line
 };
 
+template <int RR>
+__device__ __forceinline__ void zero_fill(float2 (&v)[RR]) {
+#pragma unroll
+    for (int q = 0; q < RR; ++q) v[q] = make_float2(0.f, 0.f);
+}
+template <int RR>
+__device__ __forceinline__ void load_strided(float2 (&v)[RR], const float2* __restrict__ p, int stride, bool ok) {
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < RR; ++q) v[q] = p[q * stride];
+    } else {
+        zero_fill(v);
+    }
+}
+template <int RR>
+__device__ __forceinline__ void store_strided(const float2 (&v)[RR], float2* __restrict__ p, int stride) {
+#pragma unroll
+    for (int q = 0; q < RR; ++q) p[q * stride] = v[q];
+}
+
 template <int N, int MODE>
-__global__ __launch_bounds__(B_NT) void kB(BArgs a) {
+__global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LK = BCfg<N>::LK;
-    float2* set0 = reinterpret_cast<float2*>(smem);
-    float2* set1 = set0 + LK * N;
-    float2* tw = set1 + LK * N;
-    const int tid = threadIdx.x, item = blockIdx.y, k0 = blockIdx.x * LK;
-    const int nl = min(LK, a.hr - k0);                               // valid lines in this workgroup
-    for (int i = tid; i < N; i += B_NT) tw[i] = a.tw_cols[i];
+    using C = BCfg<N>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
+    static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
+    float2* lds = reinterpret_cast<float2*>(smem);
+    const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
+    const int item = blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
+    const bool valid0 = k < a.hr;
+    const bool valid = valid0 && !(a.ablate & 1);          // loads
+    const bool vst = valid0 && !(a.ablate & 2);            // stores
+    const bool nofft = a.ablate & 4;
+    const size_t loff = (size_t)k * N + j;
+    float2* const ex1[1] = { lds + (2 * lk) * C::EPITCH };
+    float2* const ex2[2] = { lds + (2 * lk) * C::EPITCH, lds + (2 * lk + 1) * C::EPITCH };
 
-    const size_t line0 = (size_t)k0 * N;
-    // ---- stage 1: primary load
-    if (MODE == B_FWD || MODE == B_FWD_ABS_INV || MODE == B_FWD_MUL_INV) {
-        const int pl = a.src_idx ? a.src_idx[item] : item;
-        const float2* src = a.src + (size_t)pl * a.src_stride + line0;
-        float2* dstset = (MODE == B_FWD_MUL_INV) ? set1 : set0;
-        for (int i = tid; i < LK * N; i += B_NT) dstset[i] = (i < nl * N) ? src[i] : make_float2(0.f, 0.f);
-        __syncthreads();
-        line_fft<N, LK, B_NT, N, false>(dstset, tw, tid);
-    } else if (MODE == B_SOLVE_INV) {
-        const float2* src = a.src + (size_t)item * a.src_stride + line0;
-        for (int i = tid; i < LK * N; i += B_NT) {
-            const bool ok = i < nl * N;
-            set0[i] = ok ? src[i] : make_float2(0.f, 0.f);
-            set1[i] = ok ? src[a.in_plane_stride + i] : make_float2(0.f, 0.f);
-        }
-        __syncthreads();
-        line_fft<N, 2 * LK, B_NT, N, false>(set0, tw, tid);
-    }
-
-    if (MODE == B_INV) {
-        const float2* src = a.src + (size_t)item * a.src_stride + line0;
-        for (int i = tid; i < LK * N; i += B_NT) set0[i] = (i < nl * N) ? src[i] : make_float2(0.f, 0.f);
-        __syncthreads();
-        line_fft<N, LK, B_NT, N, true>(set0, tw, tid);
-        float2* d = a.dst + (size_t)item * a.dst_stride + line0;
-        for (int i = tid; i < nl * N; i += B_NT) d[i] = set0[i];
-        return;
-    }
-
-    // ---- stage 2: pointwise
-    if (MODE == B_FWD) {
-        float2* dst = a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + line0;
-        for (int i = tid; i < nl * N; i += B_NT) dst[i] = set0[i];
-        return;
-    }
-    if (MODE == B_FWD_ABS_INV) {
+    if (MODE == B_FWD || MODE == B_INV) {
+        constexpr bool INV = (MODE == B_INV);
+        using D = Dir<P, INV>;
+        float2 vin[1][D::RF], vout[1][D::RL];
+        load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, D::MF, valid && j < D::MF);
+        if (!nofft) fft_chain<P, INV, 1>(vin, vout, j, ex1, INV ? a.tw_i : a.tw_f);
+        if (vst && j < D::ML)
+            store_strided(vout[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, D::ML);
+    } else if (MODE == B_FWD_ABS_INV) {
         // fft_result = FFT(image);  IFFT(fft_result.abs())   (correlation_flow.cc:91-92)
-        float2* dst = a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + line0;
-        for (int i = tid; i < LK * N; i += B_NT) {
-            const float2 f = set0[i];
-            if (i < nl * N) dst[i] = f;
-            set0[i] = make_float2(sqrtf(f.x * f.x + f.y * f.y), 0.f);
-        }
+        float2 vin[1][DF::RF], f[1][DF::RL], o[1][DI::RL];
+        load_strided(vin[0], a.src + (size_t)item * a.src_stride + loff, DF::MF, valid && j < DF::MF);
+        if (!nofft) fft_chain<P, false, 1>(vin, f, j, ex1, a.tw_f);
+        if (vst && j < DF::ML)
+            store_strided(f[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, DF::ML);
+#pragma unroll
+        for (int q = 0; q < DF::RL; ++q) f[0][q] = make_float2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
         __syncthreads();
-        line_fft<N, LK, B_NT, N, true>(set0, tw, tid);
-        float2* d2 = a.dst2 + (size_t)item * a.dst2_stride + line0;
-        for (int i = tid; i < nl * N; i += B_NT) d2[i] = set0[i];
-        return;
-    }
-    if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
+        if (!nofft) fft_chain<P, true, 1>(f, o, j, ex1, a.tw_i);
+        if (vst && j < DI::ML) store_strided(o[0], a.dst2 + (size_t)item * a.dst2_stride + loff, DI::ML);
+    } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
         // xzf = xf * zf.conjugate() for (z,z) and (x,z)   (correlation_flow.cc:210-211,220-221)
-        const float2* z = a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + line0;
-        const float2* x = nullptr;
-        if (MODE == B_MUL_INV) x = a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + line0;
-        for (int i = tid; i < LK * N; i += B_NT) {
-            float2 zz = make_float2(0.f, 0.f), xz = make_float2(0.f, 0.f);
-            if (i < nl * N) {
-                const float2 zv = z[i];
-                const float2 xv = (MODE == B_MUL_INV) ? x[i] : set1[i];
-                zz = make_float2(zv.x * zv.x + zv.y * zv.y, 0.f);
-                xz = cmulc(xv, zv);
-            }
-            set0[i] = zz; set1[i] = xz;
+        float2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
+        // the key spectrum line is needed only after the forward chain: issue its loads first (latency hidden)
+        load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
+        if (MODE == B_FWD_MUL_INV) {
+            float2 vin[1][DF::RF], x[1][DF::RL];
+            load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
+            if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+#pragma unroll
+            for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(x[0][q], zv[q]);
+            __syncthreads();
+        } else {
+            float2 xv[DI::RF];
+            load_strided(xv, a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DI::MF, valid && j < DI::MF);
+#pragma unroll
+            for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(xv[q], zv[q]);
         }
-        __syncthreads();
-        line_fft<N, 2 * LK, B_NT, N, true>(set0, tw, tid);
-        float2* d = a.dst + (size_t)item * a.dst_stride + line0;
-        for (int i = tid; i < nl * N; i += B_NT) { d[i] = set0[i]; d[a.out_plane_stride + i] = set1[i]; }
-        return;
-    }
-    if (MODE == B_SOLVE_INV) {
+#pragma unroll
+        for (int q = 0; q < DI::RF; ++q) pr[0][q] = make_float2(zv[q].x * zv[q].x + zv[q].y * zv[q].y, 0.f);
+        if (!nofft) fft_chain<P, true, 2>(pr, o, j, ex2, a.tw_i);
+        if (vst && j < DI::ML) {
+            float2* d = a.dst + (size_t)item * a.dst_stride + loff;
+            store_strided(o[0], d, DI::ML);
+            store_strided(o[1], d + a.out_plane_stride, DI::ML);
+        }
+    } else {
         // H = T/(Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l)
-        const float rzz = 1.f / __uint_as_float(a.maxbuf[2 * item + 0]);
-        const float rxz = 1.f / __uint_as_float(a.maxbuf[2 * item + 1]);
-        for (int i = tid; i < LK * N; i += B_NT) {
-            const int line = i / N, l = i - line * N;
-            const float2 kzz = set0[i], kxz = set1[i];
-            const float2 den = make_float2(kzz.x * rzz + a.lambda, kzz.y * rzz);
-            const float2 num = make_float2(kxz.x * rxz, kxz.y * rxz);
-            const float inv = 1.f / (den.x * den.x + den.y * den.y);
-            float2 g = cmulc(num, den);
-            const float sgn = ((k0 + line + l) & 1) ? -inv : inv;
-            g.x *= sgn; g.y *= sgn;
-            if (!(i < nl * N)) g = make_float2(0.f, 0.f);
-            set0[i] = g;
+        float2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
+        const float2* src = a.src + (size_t)item * a.src_stride + loff;
+        load_strided(vin[0], src, DF::MF, valid && j < DF::MF);
+        load_strided(vin[1], src + a.in_plane_stride, DF::MF, valid && j < DF::MF);
+        const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 0]));
+        const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
+        if (!nofft) fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
+        // ML is even for every plan, so (-1)^l is the same for all q: one sign per thread
+        static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
+        const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < DF::RL; ++q) {
+            const float2 den = make_float2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
+            const float2 num = make_float2(kk[1][q].x * rxz, kk[1][q].y * rxz);
+            const float inv = sg * __builtin_amdgcn_rcpf(den.x * den.x + den.y * den.y);
+            const float2 gg = cmulc(num, den);
+            g[0][q] = make_float2(gg.x * inv, gg.y * inv);
         }
+        if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
         __syncthreads();
-        line_fft<N, LK, B_NT, N, true>(set0, tw, tid);
-        float2* d = a.dst + (size_t)item * a.dst_stride + line0;
-        for (int i = tid; i < nl * N; i += B_NT) d[i] = set0[i];
-        return;
+        if (!nofft) fft_chain<P, true, 1>(g, o, j, ex1, a.tw_i);
+        if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     }
 }
 
 template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a) {
     constexpr int LK = BCfg<N>::LK;
-    dim3 grid((a.hr + LK - 1) / LK, n_items), block(B_NT);
+    dim3 grid((a.hr + LK - 1) / LK, n_items), block(BCfg<N>::NT);
+    static const bool big_lds = (BCfg<N>::BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BCfg<N>::BYTES) == hipSuccess);
+    (void)big_lds;
     hipLaunchKernelGGL((kB<N, MODE>), grid, block, BCfg<N>::BYTES, s, a);
 }
 
@@ -599,7 +682,7 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
 
 static BArgs base_bargs(PlaneGeom g, Tables t) {
     BArgs a{};
-    a.cols = g.cols; a.hr = g.hr; a.tw_cols = t.tw_cols;
+    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = g_ablate;
     return a;
 }
 

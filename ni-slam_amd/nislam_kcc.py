@@ -24,7 +24,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
-           "nik_profile_enable", "nik_profile_read"]
+           "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate"]
 
 
 class NikConfig(C.Structure):
@@ -106,6 +106,7 @@ def load():
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
         L.nik_dbg_polar.argtypes = [P, P, P]
         L.nik_profile_enable.argtypes = [P, I]
+        L.nik_dbg_set_ablate.argtypes = [I]
         L.nik_profile_read.argtypes = [P, P, I, P]
         _lib = L
     return _lib
