@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libnislam_kcc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 UNITS = [("kcc_kernels.hip", []), ("kcc_api.hip", ["-ffp-contract=off"])]
-HEADERS = ["kcc_fft.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
+HEADERS = ["kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
 
 
 def _stale(target, deps):
@@ -19,24 +19,26 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, defs=(), suffix=""):
+    """defs/suffix: tuning variants, e.g. build(defs=["-DKCC_P360=15,24"], suffix="_p360b") -> lib..._p360b.so"""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
+    lib = LIB.replace(".so", suffix + ".so")
     for src, extra in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + COMMON + extra + ["-c", s, "-o", o]
+            cmd = [HIPCC] + COMMON + extra + list(defs) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    if force or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    if force or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -44,7 +44,8 @@ struct nik_ctx {
     float2* tmpA = nullptr;              // [max_items][max spec]
     float2* kbuf = nullptr;              // [max_items][2][max spec]  (zz, xz planes)
     float2* gbuf = nullptr;              // [max_items][max spec]
-    float*  pplane = nullptr;            // [max_batch][H*W]
+    float*  splane = nullptr;            // [max_batch][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
+    size_t  s_elems = 0;
     size_t  spec_max = 0;
     Partial* partials = nullptr; int partial_stride = 0;
     unsigned* maxbuf = nullptr;          // [max_items][2]
@@ -57,7 +58,7 @@ struct nik_ctx {
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     float* d_scratch = nullptr;          // debug / import-export staging (max(real, 2*spec) floats)
     uint32_t* polar_tab = nullptr;
-    RotEntry* rot_tab = nullptr;         // [3][PD]
+    int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
     // per-stage HIP-event profiler (nik_profile_enable / nik_profile_read)
     struct StageStat { std::string name; double ms = 0; long launches = 0; double bytes = 0; };
@@ -137,7 +138,7 @@ int family_init(nik_ctx* c, Family& f, int rows, int cols) {
 inline int cv_round_f(float v) { return (int)lrintf(v); }
 
 // cv::warpPolar map (reference correlation_flow.cc:231-234) quantised as cv::remap does (1/32 px), stored
-// [PC][PD] so a polar line (fixed radius, all angles) is contiguous.  Entry: sx | sy<<11 | fx<<22 | fy<<27.
+// [PC][PD] so a polar line (fixed radius, all angles) is contiguous.  Entry: (sx*(H+2)+sy) | fx<<22 | fy<<27.
 int build_polar_table(nik_ctx* c) {
     const int PD = c->PD, PC = c->PC, H = c->H, W = c->W;
     std::vector<uint32_t> tab((size_t)PD * PC);
@@ -155,9 +156,13 @@ int build_polar_table(nik_ctx* c) {
             const float my = (float)(rhos[rho] * sp + cy);
             const int qx = cv_round_f(mx * 32), qy = cv_round_f(my * 32);
             const int sx = qx >> 5, sy = qy >> 5;
-            if (sx < 0 || sy < 0 || sx > 2046 || sy > 2046)
-                return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "polar map coordinate out of the packed range");
-            tab[(size_t)rho * PD + phi] = (uint32_t)sx | ((uint32_t)sy << 11) | ((uint32_t)(qx & 31) << 22) | ((uint32_t)(qy & 31) << 27);
+            // all four taps must fall inside the zero-bordered plane S[W+1][H+2] (taps beyond the image read 0,
+            // exactly cv::remap's BORDER_CONSTANT path for a source that never leaves the image by more than 1 px)
+            if (sx < 0 || sy < 0 || sx + 1 > W || sy + 1 > H)
+                return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "polar map leaves the image by more than one pixel");
+            const uint32_t off = (uint32_t)sx * (uint32_t)(H + 2) + (uint32_t)sy;
+            if (off >= (1u << 22)) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "image too large for the packed polar table");
+            tab[(size_t)rho * PD + phi] = off | ((uint32_t)(qx & 31) << 22) | ((uint32_t)(qy & 31) << 27);
         }
     }
     HIP_TRY(c, hipMalloc(&c->polar_tab, sizeof(uint32_t) * tab.size()));
@@ -167,8 +172,11 @@ int build_polar_table(nik_ctx* c) {
 
 double normalize_degree(double a) { return a - 360 * floor((a + 180) / 360); }     // utils.cc:173-175
 
-// inverse affine matrix cv::warpAffine derives from getRotationMatrix2D(center, angle, 1)  (utils.cc:154-161)
-RotEntry rotation_entry(int H, int W, float degree_arg) {
+// Fixed-point terms of cv::warpAffine (WarpAffineInvoker, INTER_LINEAR) for RotateArray(image, degree_arg)
+// (utils.cc:154-161): the inverse of getRotationMatrix2D(center, angle, 1) in double, then
+//   adelta[c] = rint(M0*c*1024), bdelta[c] = rint(M3*c*1024), X0[r] = rint((M1*r+M2)*1024)+16, Y0[r] likewise.
+// Layout: [adelta W | bdelta W | X0 H | Y0 H].
+void rotation_terms(int H, int W, float degree_arg, int* out) {
     const float cx = (float)(W / 2.), cy = (float)(H / 2.);
     double angle = (double)degree_arg;
     angle *= 3.1415926535897932384626433832795 / 180;
@@ -181,27 +189,32 @@ RotEntry rotation_entry(int H, int W, float degree_arg) {
     const double b1 = -M[0] * M[2] - M[1] * M[5];
     const double b2 = -M[3] * M[2] - M[4] * M[5];
     M[2] = b1; M[5] = b2;
-    RotEntry e; memcpy(e.m, M, sizeof(M));
-    return e;
+    const int round_delta = 1024 / 32 / 2;
+    for (int c = 0; c < W; ++c) { out[c] = (int)lrint(M[0] * c * 1024); out[W + c] = (int)lrint(M[3] * c * 1024); }
+    for (int r = 0; r < H; ++r) {
+        out[2 * W + r] = (int)lrint((M[1] * r + M[2]) * 1024) + round_delta;
+        out[2 * W + H + r] = (int)lrint((M[4] * r + M[5]) * 1024) + round_delta;
+    }
 }
 
 // For every possible rotation arg-max row: the angles ComputePose feeds to RotateArray
 // (correlation_flow.cc:105-117).  variant 0: not_large_rotation; 1: `orig`; 2: `veri` (+180).
 int build_rot_table(nik_ctx* c) {
     const int PD = c->PD;
-    std::vector<RotEntry> tab((size_t)3 * PD);
+    const size_t per = (size_t)2 * c->W + 2 * c->H;
+    std::vector<int> tab((size_t)3 * PD * per);
     c->rot_deg.assign((size_t)3 * PD, 0.f);
     for (int row = 0; row < PD; ++row) {
         const double rots0 = -(row - PD / 2);
         float degree = (float)(rots0 * (2.0 / c->cfg.rotation_divisor) * 180);       // :105
         degree = (float)normalize_degree(degree);                                       // :106
         const float d0 = std::abs(degree) > 90 ? degree - 180 : degree;                 // :108
-        c->rot_deg[0 * PD + row] = d0;       tab[0 * PD + row] = rotation_entry(c->H, c->W, -d0);
-        c->rot_deg[1 * PD + row] = degree;   tab[1 * PD + row] = rotation_entry(c->H, c->W, -degree);
-        c->rot_deg[2 * PD + row] = degree;   tab[2 * PD + row] = rotation_entry(c->H, c->W, -degree + 180);
+        c->rot_deg[0 * PD + row] = d0;       rotation_terms(c->H, c->W, -d0, &tab[(0 * PD + row) * per]);
+        c->rot_deg[1 * PD + row] = degree;   rotation_terms(c->H, c->W, -degree, &tab[((size_t)1 * PD + row) * per]);
+        c->rot_deg[2 * PD + row] = degree;   rotation_terms(c->H, c->W, -degree + 180, &tab[((size_t)2 * PD + row) * per]);
     }
-    HIP_TRY(c, hipMalloc(&c->rot_tab, sizeof(RotEntry) * tab.size()));
-    HIP_TRY(c, hipMemcpy(c->rot_tab, tab.data(), sizeof(RotEntry) * tab.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc(&c->rot_tab, sizeof(int) * tab.size()));
+    HIP_TRY(c, hipMemcpy(c->rot_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice));
     return NIK_OK;
 }
 
@@ -270,10 +283,11 @@ void enqueue_intermedium(nik_ctx* c, int n) {
     { Stage st(c, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, c->tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
                            c->gbuf, c->spec_max); }
-    { Stage st(c, kname("kA_inv", c->H / 2, "real").c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_real(s, n, c->img.g, c->img.t, c->gbuf, c->spec_max, c->pplane, c->img.real_elems); }
+    { Stage st(c, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
+      launch_A_inv_shifted(s, n, c->img.g, c->img.t, c->gbuf, c->spec_max, c->splane, c->s_elems); }
+    launch_fix_zero(s, n, c->splane, c->s_elems, c->H, c->W);
     { Stage st(c, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
-      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, c->pplane, c->img.real_elems, c->H, c->W, c->polar_tab,
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, c->splane, c->s_elems, c->H, c->W, c->polar_tab,
                          c->tmpA, c->spec_max); }
     { Stage st(c, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, c->tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
@@ -431,7 +445,9 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     TRY_C(hipMalloc(&c->tmpA, sizeof(float2) * c->spec_max * c->max_items));
     TRY_C(hipMalloc(&c->kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
     TRY_C(hipMalloc(&c->gbuf, sizeof(float2) * c->spec_max * c->max_items));
-    TRY_C(hipMalloc(&c->pplane, sizeof(float) * c->img.real_elems * max_batch));
+    c->s_elems = (size_t)(W + 1) * (H + 2);
+    TRY_C(hipMalloc(&c->splane, sizeof(float) * c->s_elems * max_batch));
+    TRY_C(hipMemset(c->splane, 0, sizeof(float) * c->s_elems * max_batch));      // zero borders are never overwritten
     c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
     TRY_C(hipMalloc(&c->partials, sizeof(Partial) * c->partial_stride * c->max_items));
     TRY_C(hipMalloc(&c->maxbuf, sizeof(unsigned) * 2 * c->max_items));
@@ -457,7 +473,7 @@ void nik_destroy(nik_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
-    (void)hipFree(c->tmpA); (void)hipFree(c->kbuf); (void)hipFree(c->gbuf); (void)hipFree(c->pplane); (void)hipFree(c->partials);
+    (void)hipFree(c->tmpA); (void)hipFree(c->kbuf); (void)hipFree(c->gbuf); (void)hipFree(c->splane); (void)hipFree(c->partials);
     (void)hipFree(c->maxbuf); (void)hipFree(c->energy); (void)hipFree(c->rot_res); (void)hipFree(c->trans_res); (void)hipFree(c->d_idx);
     if (c->h_idx) (void)hipHostFree(c->h_idx);
     if (c->h_rot) (void)hipHostFree(c->h_rot);
@@ -721,8 +737,11 @@ int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     if ((rc = drain_pending(c)) || (rc = check_slot(c, fr, false))) return rc;
     if (!(c->slot_ready[fr] & 1)) return fail(c, NIK_ERR_NOT_READY, "frame slot %d holds no image", fr);
     hipStream_t s = c->stream;
-    const RotEntry e = rotation_entry(c->H, c->W, (float)degree2 * 0.5f);        // RotateArray(image, degree2/2)
-    launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img.real_elems, e, c->d_scratch, c->H, c->W);
+    std::vector<int> terms((size_t)2 * c->W + 2 * c->H);
+    rotation_terms(c->H, c->W, (float)degree2 * 0.5f, terms.data());             // RotateArray(image, degree2/2)
+    int* d_terms = reinterpret_cast<int*>(c->gbuf);
+    HIP_TRY(c, hipMemcpyAsync(d_terms, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
+    launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img.real_elems, d_terms, c->d_scratch, c->H, c->W);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -735,8 +754,11 @@ int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     if ((rc = drain_pending(c))) return rc;
     hipStream_t s = c->stream;
     float* d_out = reinterpret_cast<float*>(c->gbuf);
-    HIP_TRY(c, hipMemcpyAsync(c->pplane, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
-    launch_dbg_polar(s, c->pplane, c->polar_tab, d_out, c->H, c->W, c->PD, c->PC);
+    float* d_in = c->d_scratch;
+    HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
+    launch_make_shifted(s, d_in, c->splane, c->H, c->W);
+    launch_fix_zero(s, 1, c->splane, c->s_elems, c->H, c->W);
+    launch_dbg_polar(s, c->splane, c->polar_tab, d_out, c->H, c->W, c->PD, c->PC);
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(float) * c->pol.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());

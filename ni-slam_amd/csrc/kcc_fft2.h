@@ -95,13 +95,25 @@ template <int N> struct PlanFor;
 template <> struct PlanFor<30> : Plan<30, 5, 6> {};
 template <> struct PlanFor<60> : Plan<60, 6, 10> {};
 template <> struct PlanFor<120> : Plan<120, 10, 12> {};
-template <> struct PlanFor<240> : Plan<240, 15, 16> {};
-template <> struct PlanFor<360> : Plan<360, 18, 20> {};
+#ifndef KCC_P240
+#define KCC_P240 16, 15
+#endif
+#ifndef KCC_P360
+#define KCC_P360 18, 20
+#endif
+#ifndef KCC_P480
+#define KCC_P480 20, 24
+#endif
+#ifndef KCC_P640
+#define KCC_P640 8, 8, 10
+#endif
+template <> struct PlanFor<240> : Plan<240, KCC_P240> {};
+template <> struct PlanFor<360> : Plan<360, KCC_P360> {};
 template <> struct PlanFor<80> : Plan<80, 8, 10> {};
 template <> struct PlanFor<160> : Plan<160, 10, 16> {};
 template <> struct PlanFor<320> : Plan<320, 16, 20> {};
-template <> struct PlanFor<480> : Plan<480, 8, 6, 10> {};
-template <> struct PlanFor<640> : Plan<640, 8, 8, 10> {};
+template <> struct PlanFor<480> : Plan<480, KCC_P480> {};
+template <> struct PlanFor<640> : Plan<640, KCC_P640> {};
 template <> struct PlanFor<1280> : Plan<1280, 8, 10, 16> {};
 
 // Twiddle table layout (built on the host, see kcc_api.hip build_plan_tables):

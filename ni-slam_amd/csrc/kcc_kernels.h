@@ -28,10 +28,9 @@ struct KernelFn {
     float lambda;
 };
 
-// entry of the de-rotation table: inverse affine matrix of cv::warpAffine for one candidate angle
-struct RotEntry {
-    double m[6];
-};
+// De-rotation table: for every candidate angle, the fixed-point terms of cv::warpAffine's WarpAffineInvoker
+//   int adelta[W], bdelta[W], X0[H], Y0[H]      (2W + 2H ints per angle; X0/Y0 include round_delta)
+// so that the source coordinate of dst (r, c) is ((X0[r] + adelta[c]) >> 5, (Y0[r] + bdelta[c]) >> 5) in 1/32 px.
 
 // Geometry of one "plane family": real plane rows x cols (column-major: a line = one column of `rows`
 // contiguous floats), spectrum stored k-major: [rows/2+1][cols] float2 (cols contiguous).
@@ -67,14 +66,20 @@ void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
                         const int* src_idx, float2* dst, size_t dst_stride);
 // forward from the de-rotated image (RotateArray fused into the load)
 void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride,
-                      const int* img_slot, const RotEntry* rot_tab, const int* rot_index,
+                      const int* img_slot, const int* rot_tab, const int* rot_index,
                       float2* dst, size_t dst_stride);
-// forward from polar(fftshift(RemoveZeroComponent(p))) (gather fused into the load); g = polar geometry
-void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* p, size_t p_stride,
+// forward from polar(S), S = shifted zero-bordered planes [W+1][H+2] (gather fused into the load); g = polar geometry
+void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* S, size_t s_stride,
                         int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride);
 // inverse to a real plane, scaled by 1/(rows*cols)
 void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                        float* dst, size_t dst_stride);
+// inverse, /(rows*cols), written fftshift-ed into the zero-bordered planes S (column pitch rows+2)
+void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                          float* S, size_t s_stride);
+// RemoveZeroComponent patch of the shifted planes (one workgroup per item)
+void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W);
+void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
 // inverse -> /(rows*cols) -> kernel function -> running max|k| -> forward; in place on `buf`.
 // buf holds 2 planes per item (zz then xz), maxbuf 2 uints per item (float bits, zeroed by caller),
 // energy 2 floats per item (gaussian: sum|X|^2, sum|Z|^2 over the half spectrum).
@@ -116,8 +121,8 @@ void launch_rot_index(hipStream_t s, int n_items, const SurfaceResult* rot_res, 
                       int PD, int* rot_index);
 
 // debug: the two gathers on their own (no FFT)
-void launch_dbg_rot(hipStream_t s, const float* img, const RotEntry& R, float* out, int H, int W);
-void launch_dbg_polar(hipStream_t s, const float* p, const uint32_t* tab, float* out, int H, int W, int PD, int PC);
+void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W);
+void launch_dbg_polar(hipStream_t s, const float* S, const uint32_t* tab, float* out, int H, int W, int PD, int PC);
 
 // layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]
 void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols);

@@ -48,7 +48,7 @@ constexpr int A_LX = 16;     // lines per A-type workgroup (16 float2 = one 128-
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wrap_idx(int p, int len) {      // cv::borderInterpolate(BORDER_WRAP)
+__device__ __noinline__ int wrap_idx(int p, int len) {         // cv::borderInterpolate(BORDER_WRAP), general (slow) form
     if (p < 0) p -= ((p - len + 1) / len) * len;
     if (p >= len) p %= len;
     return p;
@@ -144,7 +144,7 @@ void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
 enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };
-enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4 };
+enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4, EPI_SHIFTED = 5 };
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
 struct AArgs {
@@ -152,8 +152,8 @@ struct AArgs {
     const float2* tw_f; const float2* tw_i; const float2* tw_full;
     // forward source
     const float* src; size_t src_stride; const int* src_idx;
-    const RotEntry* rot_tab; const int* rot_index;
-    int H, W; const uint32_t* polar_tab;
+    const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
+    int H, W, SP; const uint32_t* polar_tab;                 // polar source: shifted planes, column pitch SP
     // spectrum side
     float2* spec; size_t spec_stride; size_t plane_stride;
     // inverse outputs
@@ -173,36 +173,31 @@ template <int HH> struct ACfg {
     static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
 };
 
-// RotateArray (utils.cc:154-161): cv::warpAffine(INTER_LINEAR, BORDER_WRAP) with the inverse matrix of the
-// candidate angle; fixed-point coordinates exactly as OpenCV's WarpAffineInvoker.  dst pixel (r, c).
-__device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H, int W, const RotEntry& R, int r, int c) {
-    const int adelta = affine_delta(R.m[0], c);
-    const int bdelta = affine_delta(R.m[3], c);
-    const int X0 = affine_base(R.m[1], r, R.m[2]) + 16;
-    const int Y0 = affine_base(R.m[4], r, R.m[5]) + 16;
-    const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+// cv::borderInterpolate(BORDER_WRAP) for coordinates at most one period outside (the common case for a
+// rotation about the centre); anything further falls back to the general formula.
+__device__ __forceinline__ int wrap1(int p, int len) {
+    p += (p < 0) ? len : 0;
+    p -= (p >= len) ? len : 0;
+    if (__builtin_expect((unsigned)p >= (unsigned)len, 0)) p = wrap_idx(p, len);
+    return p;
+}
+// RotateArray (utils.cc:154-161): cv::warpAffine(INTER_LINEAR, BORDER_WRAP).  The fixed-point coordinate
+// terms of OpenCV's WarpAffineInvoker (adelta[c], bdelta[c], X0[r], Y0[r]) are tabulated per candidate angle on
+// the host, so the device does integer adds only.  Returns dst pixel (r, c).
+__device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H, int W, int ad, int bd, int X0, int Y0) {
+    const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
     int sx = X >> 5, sy = Y >> 5;
     sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));
-    const int xa = wrap_idx(sx, W), xb = wrap_idx(sx + 1, W);
-    const int ya = wrap_idx(sy, H), yb = wrap_idx(sy + 1, H);
-    return bilerp(img[(size_t)xa * H + ya], img[(size_t)xb * H + ya],
-                  img[(size_t)xa * H + yb], img[(size_t)xb * H + yb], X & 31, Y & 31);
+    const int xa = wrap1(sx, W), xb = wrap1(sx + 1, W);
+    const int ya = wrap1(sy, H), yb = wrap1(sy + 1, H);
+    const float* ca = img + (size_t)xa * H; const float* cb = img + (size_t)xb * H;
+    return bilerp(ca[ya], cb[ya], ca[yb], cb[yb], X & 31, Y & 31);
 }
-// value of fftshift(RemoveZeroComponent(p)) at shifted coordinates (y, x), zero outside
-// (correlation_flow.cc:79-87,93-94; circ_shift.h:131-154,238-244)
-__device__ __forceinline__ float shifted_hp(const float* __restrict__ p, int H, int W, int y, int x) {
-    if ((unsigned)y >= (unsigned)H || (unsigned)x >= (unsigned)W) return 0.f;
-    int r = y - H / 2; if (r < 0) r += H;
-    int c = x - W / 2; if (c < 0) c += W;
-    if (c == 0) return (p[(size_t)1 * H + r] + p[(size_t)(W - 1) * H + r]) * 0.5f;
-    if (r == 0) return (p[(size_t)c * H + 1] + p[(size_t)c * H + H - 1]) * 0.5f;
-    return p[(size_t)c * H + r];
-}
-// polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven remap sample
-__device__ __forceinline__ float polar_sample(const float* __restrict__ p, int H, int W, uint32_t t) {
-    const int sx = t & 0x7FF, sy = (t >> 11) & 0x7FF, fx = (t >> 22) & 31, fy = t >> 27;
-    return bilerp(shifted_hp(p, H, W, sy, sx), shifted_hp(p, H, W, sy, sx + 1),
-                  shifted_hp(p, H, W, sy + 1, sx), shifted_hp(p, H, W, sy + 1, sx + 1), fx, fy);
+// polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven cv::remap sample from
+// the shifted, zero-bordered plane S (column pitch SP).  Table entry: offset(sx*SP+sy):22 | fx:5 | fy:5.
+__device__ __forceinline__ float polar_sample(const float* __restrict__ S, int SP, uint32_t t) {
+    const float* q = S + (t & 0x3FFFFF);
+    return bilerp(q[0], q[SP], q[1], q[SP + 1], (t >> 22) & 31, t >> 27);
 }
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
@@ -299,21 +294,25 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_fwd(AArgs a) {
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
         } else if (SRC == SRC_ROT) {
             const float* img = a.src + (size_t)a.src_idx[item] * a.src_stride;
-            const RotEntry R = a.rot_tab[a.rot_index[item]];
+            const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
             const int c = x0 + line;
+            const int ad = tab[c], bd = tab[a.cols + c];
+            const int2* X0 = reinterpret_cast<const int2*>(tab + 2 * a.cols);
+            const int2* Y0 = reinterpret_cast<const int2*>(tab + 2 * a.cols + a.rows);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) {
                 const int m = j + q * D::MF;
-                vin[0][q] = make_float2(rot_sample(img, a.rows, a.cols, R, 2 * m, c), rot_sample(img, a.rows, a.cols, R, 2 * m + 1, c));
+                const int2 xr = X0[m], yr = Y0[m];
+                vin[0][q] = make_float2(rot_sample(img, a.rows, a.cols, ad, bd, xr.x, yr.x),
+                                        rot_sample(img, a.rows, a.cols, ad, bd, xr.y, yr.y));
             }
         } else {
-            const float* p = a.src + (size_t)item * a.src_stride;
-            const uint32_t* tab = a.polar_tab + (size_t)(x0 + line) * a.rows;
+            const float* S = a.src + (size_t)item * a.src_stride;
+            const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab + (size_t)(x0 + line) * a.rows);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) {
-                const int m = j + q * D::MF;
-                const uint2 t = *reinterpret_cast<const uint2*>(tab + 2 * m);
-                vin[0][q] = make_float2(polar_sample(p, a.H, a.W, t.x), polar_sample(p, a.H, a.W, t.y));
+                const uint2 t = tab[j + q * D::MF];
+                vin[0][q] = make_float2(polar_sample(S, a.SP, t.x), polar_sample(S, a.SP, t.y));
             }
         }
     }
@@ -361,7 +360,22 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
 
-    if (EPI == EPI_REAL) {
+    if (EPI == EPI_SHIFTED) {
+        // write fftshift(p) into the zero-bordered plane S (column pitch rows+2): out(r,c) at ((r+H/2)%H, (c+W/2)%W)
+        // (circ_shift.h:238-244); RemoveZeroComponent's row/column are patched afterwards by k_fix_zero.
+        if (j < DI::ML) {
+            const int H = a.rows, W = a.cols, SP = H + 2;
+            int xs = x0 + line + W / 2; if (xs >= W) xs -= W;
+            float* col = a.real_out + (size_t)item * a.real_stride + (size_t)xs * SP;
+#pragma unroll
+            for (int q = 0; q < DI::RL; ++q) {
+                int ys = 2 * (j + q * DI::ML) + H / 2; if (ys >= H) ys -= H;
+                const float v0 = vout[0][q].x * rsize, v1 = vout[0][q].y * rsize;
+                if ((H / 2) & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
+                else *reinterpret_cast<float2*>(col + ys) = make_float2(v0, v1);
+            }
+        }
+    } else if (EPI == EPI_REAL) {
         if (j < DI::ML) {
             float2* dst = reinterpret_cast<float2*>(a.real_out + (size_t)item * a.real_stride + (size_t)(x0 + line) * a.rows);
 #pragma unroll
@@ -474,7 +488,7 @@ void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 #undef CALL
 }
 void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride,
-                      const int* img_slot, const RotEntry* rot_tab, const int* rot_index, float2* dst, size_t dst_stride) {
+                      const int* img_slot, const int* rot_tab, const int* rot_index, float2* dst, size_t dst_stride) {
     AArgs a = base_args(g, t);
     a.src = arena_img; a.src_stride = img_stride; a.src_idx = img_slot; a.rot_tab = rot_tab; a.rot_index = rot_index;
     a.spec = dst; a.spec_stride = dst_stride;
@@ -482,10 +496,10 @@ void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const f
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
-void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* p, size_t p_stride,
+void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* S, size_t s_stride,
                         int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride) {
     AArgs a = base_args(g, t);
-    a.src = p; a.src_stride = p_stride; a.H = H; a.W = W; a.polar_tab = polar_tab; a.spec = dst; a.spec_stride = dst_stride;
+    a.src = S; a.src_stride = s_stride; a.H = H; a.W = W; a.SP = H + 2; a.polar_tab = polar_tab; a.spec = dst; a.spec_stride = dst_stride;
 #define CALL(HH) launchA_fwd_t<HH, SRC_POLAR>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
@@ -495,6 +509,14 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
     AArgs a = base_args(g, t);
     a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.real_out = dst; a.real_stride = dst_stride;
 #define CALL(HH) launchA_inv_t<HH, EPI_REAL>(s, n_items, 1, a)
+    DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
+}
+void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                          float* S, size_t s_stride) {
+    AArgs a = base_args(g, t);
+    a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.real_out = S; a.real_stride = s_stride;
+#define CALL(HH) launchA_inv_t<HH, EPI_SHIFTED>(s, n_items, 1, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
@@ -783,20 +805,52 @@ void launch_rot_index(hipStream_t s, int n_items, const SurfaceResult* rot_res, 
     hipLaunchKernelGGL(k_rot_index, dim3((n_items + 63) / 64), dim3(64), 0, s, n_items, rot_res, pair, variant, PD, rot_index);
 }
 
-__global__ void k_dbg_rot(const float* __restrict__ img, RotEntry R, float* __restrict__ out, int H, int W) {
+// RemoveZeroComponent (correlation_flow.cc:79-87) on the shifted plane S: p(r,c) lives at S[(c+W/2)%W][(r+H/2)%H].
+//   column c=0 (all r):  (p(r,1) + p(r,W-1))/2   -- reads the ORIGINAL columns 1 and W-1, so it runs first
+//   row r=0 (c != 0):    (p(1,c) + p(H-1,c))/2
+__global__ void k_fix_zero(float* __restrict__ Sbase, size_t s_stride, int H, int W) {
+    float* S = Sbase + (size_t)blockIdx.x * s_stride;
+    const int SP = H + 2, hx = W / 2, hy = H / 2;
+    const int x1 = (1 + hx) % W, xw = (W - 1 + hx) % W;
+    for (int ys = threadIdx.x; ys < H; ys += blockDim.x)
+        S[(size_t)hx * SP + ys] = (S[(size_t)x1 * SP + ys] + S[(size_t)xw * SP + ys]) * 0.5f;
+    __syncthreads();
+    const int y1 = (1 + hy) % H, yh = (H - 1 + hy) % H;
+    for (int xs = threadIdx.x; xs < W; xs += blockDim.x)
+        if (xs != hx) S[(size_t)xs * SP + hy] = (S[(size_t)xs * SP + y1] + S[(size_t)xs * SP + yh]) * 0.5f;
+}
+void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W) {
+    hipLaunchKernelGGL(k_fix_zero, dim3(n_items), dim3(256), 0, s, S, s_stride, H, W);
+}
+// debug: plain plane p (column-major H x W) -> shifted plane S (no zero-component fix)
+__global__ void k_make_shifted(const float* __restrict__ p, float* __restrict__ S, int H, int W) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < H * W) out[i] = rot_sample(img, H, W, R, i % H, i / H);
+    if (i < H * W) {
+        const int r = i % H, c = i / H;
+        S[(size_t)((c + W / 2) % W) * (H + 2) + (r + H / 2) % H] = p[i];
+    }
 }
-void launch_dbg_rot(hipStream_t s, const float* img, const RotEntry& R, float* out, int H, int W) {
-    hipLaunchKernelGGL(k_dbg_rot, dim3((H * W + 255) / 256), dim3(256), 0, s, img, R, out, H, W);
+void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W) {
+    hipLaunchKernelGGL(k_make_shifted, dim3((H * W + 255) / 256), dim3(256), 0, s, p, S, H, W);
 }
-__global__ void k_dbg_polar(const float* __restrict__ p, const uint32_t* __restrict__ tab, float* __restrict__ out,
-                            int H, int W, int n) {
+
+__global__ void k_dbg_rot(const float* __restrict__ img, const int* __restrict__ tab, float* __restrict__ out, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H * W) {
+        const int r = i % H, c = i / H;
+        out[i] = rot_sample(img, H, W, tab[c], tab[W + c], tab[2 * W + r], tab[2 * W + H + r]);
+    }
+}
+void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W) {
+    hipLaunchKernelGGL(k_dbg_rot, dim3((H * W + 255) / 256), dim3(256), 0, s, img, rot_tab, out, H, W);
+}
+__global__ void k_dbg_polar(const float* __restrict__ S, const uint32_t* __restrict__ tab, float* __restrict__ out,
+                            int SP, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // out is column-major PD x PC == tab order [PC][PD]
-    if (i < n) out[i] = polar_sample(p, H, W, tab[i]);
+    if (i < n) out[i] = polar_sample(S, SP, tab[i]);
 }
-void launch_dbg_polar(hipStream_t s, const float* p, const uint32_t* tab, float* out, int H, int W, int PD, int PC) {
-    hipLaunchKernelGGL(k_dbg_polar, dim3((PD * PC + 255) / 256), dim3(256), 0, s, p, tab, out, H, W, PD * PC);
+void launch_dbg_polar(hipStream_t s, const float* S, const uint32_t* tab, float* out, int H, int W, int PD, int PC) {
+    hipLaunchKernelGGL(k_dbg_polar, dim3((PD * PC + 255) / 256), dim3(256), 0, s, S, tab, out, H + 2, PD * PC);
 }
 
 __global__ void k_transpose_c(const float2* __restrict__ src, float2* __restrict__ dst, int R, int C) {

@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnislam_kcc_hip.so")
+LIB_PATH = os.environ.get("NIK_LIB") or os.path.join(_HERE, "libnislam_kcc_hip.so")   # NIK_LIB: tuning variants
 
 NIK_OK = 0
 NIK_ERR_INVALID_ARG, NIK_ERR_UNSUPPORTED_SIZE, NIK_ERR_INVALID_KERNEL = -1, -2, -3
