@@ -80,8 +80,11 @@ void nik_destroy(nik_ctx* ctx);
 const char* nik_last_error(const nik_ctx* ctx);      /* ctx may be NULL: last create() error */
 /* geometry queries (H, W, PD, PC, max_batch, max_frames) */
 int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
-/* stream the context launches on (a hipStream_t, returned as void*) */
+/* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
+/* A batched call is split over up to `n` concurrent HIP streams ("lanes", default 2 or $NIK_STREAMS, max 4);
+ * returns the number now active.  Outputs do not depend on it. */
+int  nik_set_streams(nik_ctx* ctx, int n);
 int  nik_synchronize(nik_ctx* ctx);
 
 /* ---- ComputeIntermedium (correlation_flow.cc:89-95) ------------------------------------- */

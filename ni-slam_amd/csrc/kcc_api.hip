@@ -1,12 +1,19 @@
 // kcc_api.hip -- C ABI of libnislam_kcc_hip.so (see include/nislam_kcc.h).
-// Host side: context, device-resident keyframe store, batched stage scheduling on one HIP stream.
+// Host side: context, device-resident keyframe store, batched stage scheduling.
 // Mirrors CorrelationFlow (reference include/correlation_flow.h:8-33, src/correlation_flow.cc:37-143).
+//
+// Scheduling: a context owns NL "lanes" (HIP stream + private work buffers).  A batched call is split into
+// NL contiguous chunks, one per lane, so the kernels of different chunks overlap on the GPU (the memory-bound
+// phases of one chunk hide under the ALU/LDS-bound phases of another).  Each lane keeps a ring of two
+// in-flight calls (pinned index / result staging + a completion event), so the host can queue the next batch
+// while the previous one is still running; results are finalised lazily (nik_synchronize or ring reuse).
 #include "../../include/nislam_kcc.h"
 #include "kcc_kernels.h"
 
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +32,38 @@ struct Family {                 // one plane geometry with its tables
     float2* d_tw[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
+// index arrays of one call (each cap_items ints)
+enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_PAIR = 3, IX_VARIANT = 4, IX_TIMG = 5, IX_TKEY = 6, IX_ROTIDX = 7, IX_COUNT = 8 };
+
+struct Call {                   // one in-flight call on a lane
+    int* h_idx = nullptr;                                   // pinned staging, IX_COUNT * cap_items
+    SurfaceResult* h_rot = nullptr; SurfaceResult* h_trans = nullptr;   // pinned result staging
+    hipEvent_t done = nullptr;
+    bool busy = false;          // `done` has been recorded and not yet waited for
+    bool has_pose = false; int n = 0, n_hyp = 1; nik_pose_result* res = nullptr;
+};
+
+struct Lane {
+    hipStream_t stream = nullptr;
+    hipEvent_t write_ev = nullptr;      // recorded after the lane's latest frame-slot writes
+    unsigned long write_seq = 0;
+    std::vector<unsigned long> seen;    // seen[w] = write_seq of lane w this lane has already waited for
+    hipEvent_t tail_ev = nullptr;       // recorded at the end of the lane's latest call
+    unsigned long call_seq = 0;
+    std::vector<unsigned long> seen_tail;   // seen_tail[r] = call_seq of lane r this lane has already waited for
+    int cap_items = 0;
+    float2* tmpA = nullptr;             // [cap_items][max spec]
+    float2* kbuf = nullptr;             // [cap_items][2][max spec]  (zz, xz planes)
+    float2* gbuf = nullptr;             // [cap_items][max spec]
+    float*  splane = nullptr;           // [cap_pairs][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
+    Partial* partials = nullptr;
+    unsigned* maxbuf = nullptr; float* energy = nullptr;
+    SurfaceResult* rot_res = nullptr; SurfaceResult* trans_res = nullptr;
+    int* d_idx = nullptr;
+    Call ring[2]; int next = 0;
+    Call* cur = nullptr;                // call being enqueued
+};
+
 }  // namespace
 
 struct nik_ctx {
@@ -32,31 +71,19 @@ struct nik_ctx {
     int H = 0, W = 0, PD = 0, PC = 0;
     int max_batch = 0, max_frames = 0, device = 0;
     int max_items = 0;          // 2*max_batch (two hypotheses per pair in large-rotation mode)
-    hipStream_t stream = nullptr;
-    hipEvent_t idx_event = nullptr;
     std::string err;
 
     Family img, pol;
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
     float* arena_img = nullptr; float2* arena_F = nullptr; float2* arena_P = nullptr;
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
-    // work buffers
-    float2* tmpA = nullptr;              // [max_items][max spec]
-    float2* kbuf = nullptr;              // [max_items][2][max spec]  (zz, xz planes)
-    float2* gbuf = nullptr;              // [max_items][max spec]
-    float*  splane = nullptr;            // [max_batch][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
-    size_t  s_elems = 0;
-    size_t  spec_max = 0;
-    Partial* partials = nullptr; int partial_stride = 0;
-    unsigned* maxbuf = nullptr;          // [max_items][2]
-    float* energy = nullptr;             // [max_items][2]
-    SurfaceResult* rot_res = nullptr;    // [max_batch]
-    SurfaceResult* trans_res = nullptr;  // [max_items]
-    int* d_idx = nullptr;                // device int scratch: 6 arrays of max_items
-    int* h_idx = nullptr;                // pinned mirror
-    SurfaceResult* h_rot = nullptr; SurfaceResult* h_trans = nullptr;   // pinned
+    std::vector<int8_t> slot_lane;       // lane that last wrote the slot (-1: none / host import)
+    std::vector<unsigned long> slot_seq; // that lane's write_seq at the time
+    std::vector<unsigned long> slot_rd;  // [slot][4]: call_seq of each lane's latest call that read the slot
+    size_t s_elems = 0, spec_max = 0; int partial_stride = 0;
+    std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
-    float* d_scratch = nullptr;          // debug / import-export staging (max(real, 2*spec) floats)
+    float* d_scratch = nullptr;          // debug / import-export staging
     uint32_t* polar_tab = nullptr;
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
@@ -67,8 +94,6 @@ struct nik_ctx {
     std::vector<StageStat> prof_stats;
     std::vector<StageRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
-    // pending asynchronous batch
-    struct Pending { bool active = false; int n = 0; int n_hyp = 1; nik_pose_result* res = nullptr; } pending;
 };
 
 namespace {
@@ -218,20 +243,11 @@ int build_rot_table(nik_ctx* c) {
     return NIK_OK;
 }
 
-// index scratch layout (each max_items ints)
-enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_PAIR = 3, IX_VARIANT = 4, IX_TIMG = 5, IX_TKEY = 6, IX_ROTIDX = 7, IX_COUNT = 8 };
-inline int* didx(nik_ctx* c, int which) { return c->d_idx + (size_t)which * c->max_items; }
-inline int* hidx(nik_ctx* c, int which) { return c->h_idx + (size_t)which * c->max_items; }
+inline int* didx(Lane& L, int which) { return L.d_idx + (size_t)which * L.cap_items; }
+inline int* hidx(Lane& L, int which) { return L.cur->h_idx + (size_t)which * L.cap_items; }
 
-// The pinned staging arrays are reused by every call: wait until the previous uploads have been consumed
-// (a tiny H2D copy each -- this never waits for the kernels queued behind them).
-int begin_idx(nik_ctx* c) {
-    HIP_TRY(c, hipEventSynchronize(c->idx_event));
-    return NIK_OK;
-}
-int upload_idx(nik_ctx* c, int which, int n) {
-    HIP_TRY(c, hipMemcpyAsync(didx(c, which), hidx(c, which), sizeof(int) * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipEventRecord(c->idx_event, c->stream));
+int upload_idx(nik_ctx* c, Lane& L, int which, int n) {
+    HIP_TRY(c, hipMemcpyAsync(didx(L, which), hidx(L, which), sizeof(int) * n, hipMemcpyHostToDevice, L.stream));
     return NIK_OK;
 }
 
@@ -247,110 +263,6 @@ KernelFn kernel_fn(const nik_ctx* c) {
     return fn;
 }
 
-// ---- stage profiler: brackets one kernel launch with HIP events on the launch stream -----------------
-struct Stage {
-    nik_ctx* c; int rec = -1;
-    Stage(nik_ctx* c_, const char* name, double bytes) : c(c_) {
-        if (!c->prof_on) return;
-        int id = -1;
-        for (size_t i = 0; i < c->prof_stats.size(); ++i) if (c->prof_stats[i].name == name) { id = (int)i; break; }
-        if (id < 0) { c->prof_stats.push_back({}); id = (int)c->prof_stats.size() - 1; c->prof_stats[id].name = name; }
-        c->prof_stats[id].launches += 1; c->prof_stats[id].bytes += bytes;
-        nik_ctx::StageRec r; r.stage = id;
-        for (hipEvent_t* e : { &r.a, &r.b }) {
-            if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
-            else if (hipEventCreate(e) != hipSuccess) return;
-        }
-        (void)hipEventRecord(r.a, c->stream);
-        c->prof_recs.push_back(r); rec = (int)c->prof_recs.size() - 1;
-    }
-    ~Stage() { if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, c->stream); }
-};
-std::string kname(const char* base, int len, const char* mode) {
-    char b[64]; snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode); return b;
-}
-inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
-inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
-
-// ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
-// arena slots listed in d_idx[IX_DST].
-void enqueue_intermedium(nik_ctx* c, int n) {
-    hipStream_t s = c->stream;
-    const int* dst = didx(c, IX_DST);
-    const Family& I = c->img; const Family& P = c->pol;
-    { Stage st(c, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
-      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img.real_elems, dst, c->tmpA, c->spec_max); }
-    { Stage st(c, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
-      launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, c->tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
-                           c->gbuf, c->spec_max); }
-    { Stage st(c, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_shifted(s, n, c->img.g, c->img.t, c->gbuf, c->spec_max, c->splane, c->s_elems); }
-    launch_fix_zero(s, n, c->splane, c->s_elems, c->H, c->W);
-    { Stage st(c, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
-      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, c->splane, c->s_elems, c->H, c->W, c->polar_tab,
-                         c->tmpA, c->spec_max); }
-    { Stage st(c, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
-      launch_B_fwd(s, n, c->pol.g, c->pol.t, c->tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
-}
-
-// EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
-void enqueue_estimate(nik_ctx* c, int n, Family& f, bool x_fwd, const float2* xsrc, size_t x_stride, const int* x_idx,
-                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out) {
-    hipStream_t s = c->stream;
-    const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
-    (void)hipMemsetAsync(c->maxbuf, 0, sizeof(unsigned) * 2 * n, s);
-    if (c->cfg.kernel == 1 && !x_fwd)
-        launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, c->energy);
-    { Stage st(c, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
-      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, c->kbuf, item_stride, plane_stride); }
-    { Stage st(c, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
-      launch_A_inv_kernel_fwd(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, kernel_fn(c), c->maxbuf, c->energy); }
-    { Stage st(c, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
-      launch_B_solve_inv(s, n, f.g, f.t, c->kbuf, item_stride, plane_stride, c->maxbuf, c->cfg.lambda, c->gbuf, c->spec_max); }
-    const int nb = argmax_blocks(f.g);
-    { Stage st(c, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
-      launch_A_inv_argmax(s, n, f.g, f.t, c->gbuf, c->spec_max, c->partials, c->partial_stride); }
-    launch_finalize(s, n, c->partials, c->partial_stride, nb, out);
-}
-
-// ComputePose (correlation_flow.cc:97-143) for n pairs; key/cur slots in d_idx[IX_KEY]/[IX_CUR].
-// Leaves raw surface results in h_rot / h_trans (valid after the stream is synchronised).
-int enqueue_pose(nik_ctx* c, int n, int not_large_rotation) {
-    hipStream_t s = c->stream;
-    const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
-    // rotation stage: z = key polar spectrum, x = current polar spectrum
-    enqueue_estimate(c, n, c->pol, false, c->arena_P, c->pol.spec_elems, didx(c, IX_CUR),
-                     c->arena_P, c->pol.spec_elems, didx(c, IX_KEY), c->rot_res);
-    // translation items (one per pair and hypothesis)
-    for (int t = 0; t < nt; ++t) {
-        const int p = t / n_hyp, hyp = t % n_hyp;
-        hidx(c, IX_PAIR)[t] = p;
-        hidx(c, IX_VARIANT)[t] = not_large_rotation ? 0 : 1 + hyp;
-        hidx(c, IX_TIMG)[t] = hidx(c, IX_CUR)[p];
-        hidx(c, IX_TKEY)[t] = hidx(c, IX_KEY)[p];
-    }
-    int rc;
-    if ((rc = upload_idx(c, IX_PAIR, nt)) || (rc = upload_idx(c, IX_VARIANT, nt)) ||
-        (rc = upload_idx(c, IX_TIMG, nt)) || (rc = upload_idx(c, IX_TKEY, nt))) return rc;
-    launch_rot_index(s, nt, c->rot_res, didx(c, IX_PAIR), didx(c, IX_VARIANT), c->PD, didx(c, IX_ROTIDX));
-    // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
-    { Stage st(c, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
-      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(c, IX_TIMG), c->rot_tab,
-                       didx(c, IX_ROTIDX), c->tmpA, c->spec_max); }
-    if (c->cfg.kernel == 1) {
-        // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
-        launch_B_fwd(s, nt, c->img.g, c->img.t, c->tmpA, c->spec_max, c->tmpA, c->spec_max, nullptr);
-        enqueue_estimate(c, nt, c->img, false, c->tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(c, IX_TKEY), c->trans_res);
-    } else {
-        enqueue_estimate(c, nt, c->img, true, c->tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(c, IX_TKEY), c->trans_res);
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->h_rot, c->rot_res, sizeof(SurfaceResult) * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(c->h_trans, c->trans_res, sizeof(SurfaceResult) * nt, hipMemcpyDeviceToHost, s));
-    return NIK_OK;
-}
-
 // GetInfo (correlation_flow.cc:238-243) from single-pass moments
 float psr_from(const SurfaceResult& r, long n) {
     const double m = (r.sum - (double)r.peak) / (double)(n - 1);
@@ -359,17 +271,17 @@ float psr_from(const SurfaceResult& r, long n) {
     return (float)(((double)r.peak - m) / ((double)(float)sqrt(var) + 1e-7));
 }
 
-// host tail of ComputePose (:105-138) from the raw arg-max results
-void finalize_pose(nik_ctx* c, int i, int n_hyp, nik_pose_result* out) {
-    const int PD = c->PD, H = c->H, W = c->W;
+// host tail of ComputePose (:105-138) from the raw arg-max results of pair i of a call
+void finalize_pose(nik_ctx* c, const Call& call, int i, nik_pose_result* out) {
+    const int PD = c->PD, H = c->H, W = c->W, n_hyp = call.n_hyp;
     nik_pose_result r; memset(&r, 0, sizeof(r));
-    const SurfaceResult& rr = c->h_rot[i];
+    const SurfaceResult& rr = call.h_rot[i];
     r.rot_row = rr.idx % PD; r.rot_col = rr.idx / PD;
     r.psr_rot = psr_from(rr, (long)PD * c->PC);
     r.n_hyp = n_hyp;
     float degree; float info_trans; double trans0, trans1;
     auto tr = [&](int hyp, double& t0, double& t1) {
-        const SurfaceResult& s = c->h_trans[i * n_hyp + hyp];
+        const SurfaceResult& s = call.h_trans[i * n_hyp + hyp];
         r.trans_row[hyp] = s.idx % H; r.trans_col[hyp] = s.idx / H;
         r.psr_trans[hyp] = psr_from(s, (long)H * W);
         t0 = -(r.trans_row[hyp] - H / 2); t1 = -(r.trans_col[hyp] - W / 2);
@@ -392,18 +304,232 @@ void finalize_pose(nik_ctx* c, int i, int n_hyp, nik_pose_result* out) {
     *out = r;
 }
 
-int drain_pending(nik_ctx* c) {
-    if (!c->pending.active) return NIK_OK;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->pending.res)
-        for (int i = 0; i < c->pending.n; ++i) finalize_pose(c, i, c->pending.n_hyp, c->pending.res + i);
-    c->pending.active = false;
+// wait for one in-flight call and hand its results to the caller
+int retire(nik_ctx* c, Call& call) {
+    if (!call.busy) return NIK_OK;
+    HIP_TRY(c, hipEventSynchronize(call.done));
+    if (call.has_pose && call.res)
+        for (int i = 0; i < call.n; ++i) finalize_pose(c, call, i, call.res + i);
+    call.busy = false; call.has_pose = false; call.res = nullptr;
+    return NIK_OK;
+}
+
+int drain_all(nik_ctx* c) {
+    for (Lane& L : c->lanes)
+        for (int k = 0; k < 2; ++k) {               // older call first
+            int rc = retire(c, L.ring[(L.next + k) & 1]);
+            if (rc) return rc;
+        }
+    return NIK_OK;
+}
+
+// start a call on a lane: take the older ring entry (retiring what it held)
+int begin_call(nik_ctx* c, Lane& L) {
+    Call& call = L.ring[L.next];
+    int rc = retire(c, call);
+    if (rc) return rc;
+    L.cur = &call; L.next ^= 1; L.call_seq += 1;
+    return NIK_OK;
+}
+int end_call(nik_ctx* c, Lane& L) {
+    HIP_TRY(c, hipEventRecord(L.cur->done, L.stream));
+    HIP_TRY(c, hipEventRecord(L.tail_ev, L.stream));
+    L.cur->busy = true;
+    return NIK_OK;
+}
+
+// lane L is about to read frame slot f: order it after the lane that wrote f (if different and not yet seen)
+int depend_on_slot(nik_ctx* c, Lane& L, int li, nik_frame f) {
+    const int w = c->slot_lane[f];
+    if (w < 0 || w == li) return NIK_OK;
+    if (L.seen[w] >= c->slot_seq[f]) return NIK_OK;
+    HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lanes[w].write_ev, 0));
+    L.seen[w] = c->lanes[w].write_seq;
+    return NIK_OK;
+}
+// lane L reads slot f in its current call
+inline void note_read(nik_ctx* c, Lane& L, int li, nik_frame f) { c->slot_rd[(size_t)f * 4 + li] = L.call_seq; }
+// lane L is about to overwrite slot f: order it after other lanes' calls that read or wrote it
+int depend_for_write(nik_ctx* c, Lane& L, int li, nik_frame f) {
+    int rc = depend_on_slot(c, L, li, f);
+    if (rc) return rc;
+    for (int r = 0; r < (int)c->lanes.size(); ++r) {
+        if (r == li) continue;
+        if (c->slot_rd[(size_t)f * 4 + r] > L.seen_tail[r]) {
+            HIP_TRY(c, hipStreamWaitEvent(L.stream, c->lanes[r].tail_ev, 0));
+            L.seen_tail[r] = c->lanes[r].call_seq;
+        }
+    }
+    return NIK_OK;
+}
+int mark_written(nik_ctx* c, Lane& L, int li, const int* slots, int n) {
+    L.write_seq += 1;
+    HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
+    for (int i = 0; i < n; ++i) { c->slot_lane[slots[i]] = (int8_t)li; c->slot_seq[slots[i]] = L.write_seq; c->slot_ready[slots[i]] = 3; }
+    return NIK_OK;
+}
+
+// ---- stage profiler: brackets one kernel launch with HIP events on the launch stream -----------------
+struct Stage {
+    nik_ctx* c; hipStream_t s; int rec = -1;
+    Stage(nik_ctx* c_, Lane& L, const char* name, double bytes) : c(c_), s(L.stream) {
+        if (!c->prof_on) return;
+        int id = -1;
+        for (size_t i = 0; i < c->prof_stats.size(); ++i) if (c->prof_stats[i].name == name) { id = (int)i; break; }
+        if (id < 0) { c->prof_stats.push_back({}); id = (int)c->prof_stats.size() - 1; c->prof_stats[id].name = name; }
+        c->prof_stats[id].launches += 1; c->prof_stats[id].bytes += bytes;
+        nik_ctx::StageRec r; r.stage = id;
+        for (hipEvent_t* e : { &r.a, &r.b }) {
+            if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+            else if (hipEventCreate(e) != hipSuccess) return;
+        }
+        (void)hipEventRecord(r.a, s);
+        c->prof_recs.push_back(r); rec = (int)c->prof_recs.size() - 1;
+    }
+    ~Stage() { if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, s); }
+};
+std::string kname(const char* base, int len, const char* mode) {
+    char b[64]; snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode); return b;
+}
+inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
+inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
+
+// ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
+// arena slots listed in d_idx[IX_DST].
+void enqueue_intermedium(nik_ctx* c, Lane& L, int n) {
+    hipStream_t s = L.stream;
+    const int* dst = didx(L, IX_DST);
+    const Family& I = c->img; const Family& P = c->pol;
+    { Stage st(c, L, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
+      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img.real_elems, dst, L.tmpA, c->spec_max); }
+    { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
+      launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
+                           L.gbuf, c->spec_max); }
+    { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
+      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems); }
+    launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
+    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab,
+                         L.tmpA, c->spec_max); }
+    { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
+      launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
+}
+
+// EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
+void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const float2* xsrc, size_t x_stride, const int* x_idx,
+                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out) {
+    hipStream_t s = L.stream;
+    const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
+    (void)hipMemsetAsync(L.maxbuf, 0, sizeof(unsigned) * 2 * n, s);
+    if (c->cfg.kernel == 1 && !x_fwd)
+        launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
+    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
+      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride); }
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
+      launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy); }
+    { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
+      launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max); }
+    const int nb = argmax_blocks(f.g);
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
+      launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
+    launch_finalize(s, n, L.partials, c->partial_stride, nb, out);
+}
+
+// ComputePose (correlation_flow.cc:97-143) for n pairs; key/cur slots in the lane's IX_KEY / IX_CUR arrays.
+// Leaves raw surface results in the call's h_rot / h_trans (valid after its `done` event).
+int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation) {
+    hipStream_t s = L.stream;
+    const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
+    // rotation stage: z = key polar spectrum, x = current polar spectrum
+    enqueue_estimate(c, L, n, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
+                     c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res);
+    // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
+    launch_rot_index(s, nt, L.rot_res, didx(L, IX_PAIR), didx(L, IX_VARIANT), c->PD, didx(L, IX_ROTIDX));
+    // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
+    { Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
+      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(L, IX_TIMG), c->rot_tab,
+                       didx(L, IX_ROTIDX), L.tmpA, c->spec_max); }
+    if (c->cfg.kernel == 1) {
+        // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
+        launch_B_fwd(s, nt, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
+        enqueue_estimate(c, L, nt, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
+                         didx(L, IX_TKEY), L.trans_res);
+    } else {
+        enqueue_estimate(c, L, nt, c->img, true, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
+                         didx(L, IX_TKEY), L.trans_res);
+    }
+    HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * n, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipMemcpyAsync(L.cur->h_trans, L.trans_res, sizeof(SurfaceResult) * nt, hipMemcpyDeviceToHost, s));
+    return NIK_OK;
+}
+
+// fill + upload every index array a pose call needs, in ONE host-to-device copy (arrays are contiguous)
+int stage_pose_indices(nik_ctx* c, Lane& L, int n, const nik_frame* keys, const nik_frame* curs, int not_large_rotation,
+                       bool with_dst) {
+    const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
+    for (int i = 0; i < n; ++i) { hidx(L, IX_KEY)[i] = keys[i]; hidx(L, IX_CUR)[i] = curs[i]; if (with_dst) hidx(L, IX_DST)[i] = curs[i]; }
+    for (int t = 0; t < nt; ++t) {
+        const int p = t / n_hyp, hyp = t % n_hyp;
+        hidx(L, IX_PAIR)[t] = p;
+        hidx(L, IX_VARIANT)[t] = not_large_rotation ? 0 : 1 + hyp;
+        hidx(L, IX_TIMG)[t] = curs[p];
+        hidx(L, IX_TKEY)[t] = keys[p];
+    }
+    HIP_TRY(c, hipMemcpyAsync(L.d_idx, L.cur->h_idx, sizeof(int) * (size_t)L.cap_items * IX_ROTIDX, hipMemcpyHostToDevice, L.stream));
     return NIK_OK;
 }
 
 int check_kernel(nik_ctx* c) {
     if (c->cfg.kernel != 0 && c->cfg.kernel != 1) return fail(c, NIK_ERR_INVALID_KERNEL, "Received invalid kernel type");
     return NIK_OK;
+}
+
+// contiguous chunk [b, e) of n items for lane li of nl
+inline void chunk_of(int n, int nl, int li, int& b, int& e) {
+    const int per = (n + nl - 1) / nl;
+    b = std::min(n, li * per); e = std::min(n, b + per);
+}
+inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->active_lanes, n)); }
+
+int lane_alloc(nik_ctx* c, Lane& L, int nl) {
+    L.cap_items = c->max_items;
+    L.seen.assign(nl, 0); L.seen_tail.assign(nl, 0);
+    HIP_TRY(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreateWithFlags(&L.write_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&L.tail_ev, hipEventDisableTiming));
+    HIP_TRY(c, hipMalloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.gbuf, sizeof(float2) * c->spec_max * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * c->s_elems * c->max_batch));
+    HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * c->s_elems * c->max_batch));      // zero borders are never overwritten
+    HIP_TRY(c, hipMalloc(&L.partials, sizeof(Partial) * c->partial_stride * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.maxbuf, sizeof(unsigned) * 2 * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.energy, sizeof(float) * 2 * c->max_items));
+    HIP_TRY(c, hipMemset(L.energy, 0, sizeof(float) * 2 * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.rot_res, sizeof(SurfaceResult) * c->max_batch));
+    HIP_TRY(c, hipMalloc(&L.trans_res, sizeof(SurfaceResult) * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.d_idx, sizeof(int) * c->max_items * IX_COUNT));
+    for (Call& call : L.ring) {
+        HIP_TRY(c, hipHostMalloc(&call.h_idx, sizeof(int) * c->max_items * IX_COUNT));
+        HIP_TRY(c, hipHostMalloc(&call.h_rot, sizeof(SurfaceResult) * c->max_batch));
+        HIP_TRY(c, hipHostMalloc(&call.h_trans, sizeof(SurfaceResult) * c->max_items));
+        HIP_TRY(c, hipEventCreateWithFlags(&call.done, hipEventDisableTiming));
+    }
+    return NIK_OK;
+}
+void lane_free(Lane& L) {
+    if (L.stream) (void)hipStreamSynchronize(L.stream);
+    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.partials);
+    (void)hipFree(L.maxbuf); (void)hipFree(L.energy); (void)hipFree(L.rot_res); (void)hipFree(L.trans_res); (void)hipFree(L.d_idx);
+    for (Call& call : L.ring) {
+        if (call.h_idx) (void)hipHostFree(call.h_idx);
+        if (call.h_rot) (void)hipHostFree(call.h_rot);
+        if (call.h_trans) (void)hipHostFree(call.h_trans);
+        if (call.done) (void)hipEventDestroy(call.done);
+    }
+    if (L.write_ev) (void)hipEventDestroy(L.write_ev);
+    if (L.tail_ev) (void)hipEventDestroy(L.tail_ev);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
 }
 
 }  // namespace
@@ -422,6 +548,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (!fft_half_supported(H / 2) || !fft_half_supported(PD / 2) || !fft_line_supported(W) || !fft_line_supported(PC))
         return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "FFT length not instantiated for %dx%d / polar %dx%d", H, W, PD, PC);
     if (W % 16 || PC % 16) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "width and rotation_channel must be multiples of 16");
+    if (H / 2 + 2 > W || W / 2 + 2 > H)      // keeps every de-rotated source coordinate within one period (single-step BORDER_WRAP)
+        return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "aspect ratio beyond 2:1 is not supported");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, NIK_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
@@ -433,36 +561,24 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     auto bail = [&](int rc) { g_create_error = c->err; nik_destroy(c); return rc; };
 #define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, NIK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(NIK_ERR_HIP); } } while (0)
     TRY_C(hipSetDevice(device));
-    TRY_C(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    TRY_C(hipEventCreateWithFlags(&c->idx_event, hipEventDisableTiming));
     int rc;
     if ((rc = family_init(c, c->img, H, W)) || (rc = family_init(c, c->pol, PD, PC))) return bail(rc);
     c->spec_max = std::max(c->img.spec_elems, c->pol.spec_elems);
+    c->s_elems = (size_t)(W + 1) * (H + 2);
+    c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
     TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img.real_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
-    c->slot_ready.assign(max_frames, 0);
-    TRY_C(hipMalloc(&c->tmpA, sizeof(float2) * c->spec_max * c->max_items));
-    TRY_C(hipMalloc(&c->kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
-    TRY_C(hipMalloc(&c->gbuf, sizeof(float2) * c->spec_max * c->max_items));
-    c->s_elems = (size_t)(W + 1) * (H + 2);
-    TRY_C(hipMalloc(&c->splane, sizeof(float) * c->s_elems * max_batch));
-    TRY_C(hipMemset(c->splane, 0, sizeof(float) * c->s_elems * max_batch));      // zero borders are never overwritten
-    c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
-    TRY_C(hipMalloc(&c->partials, sizeof(Partial) * c->partial_stride * c->max_items));
-    TRY_C(hipMalloc(&c->maxbuf, sizeof(unsigned) * 2 * c->max_items));
-    TRY_C(hipMalloc(&c->energy, sizeof(float) * 2 * c->max_items));
-    TRY_C(hipMemset(c->energy, 0, sizeof(float) * 2 * c->max_items));
-    TRY_C(hipMalloc(&c->rot_res, sizeof(SurfaceResult) * max_batch));
-    TRY_C(hipMalloc(&c->trans_res, sizeof(SurfaceResult) * c->max_items));
-    TRY_C(hipMalloc(&c->d_idx, sizeof(int) * c->max_items * IX_COUNT));
-    TRY_C(hipHostMalloc(&c->h_idx, sizeof(int) * c->max_items * IX_COUNT));
-    TRY_C(hipHostMalloc(&c->h_rot, sizeof(SurfaceResult) * max_batch));
-    TRY_C(hipHostMalloc(&c->h_trans, sizeof(SurfaceResult) * c->max_items));
+    c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
+    int nl = 2;
+    if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);
+    nl = std::max(1, std::min(4, nl));
+    c->lanes.resize(nl); c->active_lanes = nl;
+    for (Lane& L : c->lanes) if ((rc = lane_alloc(c, L, nl))) return bail(rc);
     TRY_C(hipMalloc(&c->d_u8, (size_t)H * W));
     TRY_C(hipMalloc(&c->d_scratch, sizeof(float) * std::max(c->img.real_elems, 2 * c->spec_max) * 2));
     if ((rc = build_polar_table(c)) || (rc = build_rot_table(c))) return bail(rc);
-    TRY_C(hipStreamSynchronize(c->stream));
+    TRY_C(hipDeviceSynchronize());
 #undef TRY_C
     *out = c;
     return NIK_OK;
@@ -470,19 +586,12 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
 
 void nik_destroy(nik_ctx* c) {
     if (!c) return;
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (Lane& L : c->lanes) lane_free(L);
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
-    (void)hipFree(c->tmpA); (void)hipFree(c->kbuf); (void)hipFree(c->gbuf); (void)hipFree(c->splane); (void)hipFree(c->partials);
-    (void)hipFree(c->maxbuf); (void)hipFree(c->energy); (void)hipFree(c->rot_res); (void)hipFree(c->trans_res); (void)hipFree(c->d_idx);
-    if (c->h_idx) (void)hipHostFree(c->h_idx);
-    if (c->h_rot) (void)hipHostFree(c->h_rot);
-    if (c->h_trans) (void)hipHostFree(c->h_trans);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->rot_tab);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
-    if (c->idx_event) (void)hipEventDestroy(c->idx_event);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -493,13 +602,21 @@ int nik_get_dims(const nik_ctx* c, int dims[6]) {
     dims[0] = c->H; dims[1] = c->W; dims[2] = c->PD; dims[3] = c->PC; dims[4] = c->max_batch; dims[5] = c->max_frames;
     return NIK_OK;
 }
-void* nik_stream(const nik_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* nik_stream(const nik_ctx* c) { return c ? (void*)c->lanes[0].stream : nullptr; }
+
+int nik_set_streams(nik_ctx* c, int n) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    c->active_lanes = std::max(1, std::min((int)c->lanes.size(), n));
+    return c->active_lanes;
+}
 
 int nik_synchronize(nik_ctx* c) {
     if (!c) return NIK_ERR_INVALID_ARG;
-    int rc = drain_pending(c);
+    int rc = drain_all(c);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (Lane& L : c->lanes) HIP_TRY(c, hipStreamSynchronize(L.stream));
     return NIK_OK;
 }
 
@@ -508,14 +625,21 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
     int rc;
-    if ((rc = drain_pending(c)) || (rc = begin_idx(c))) return rc;
-    for (int i = 0; i < n; ++i) { if ((rc = check_slot(c, dst[i], false))) return rc; hidx(c, IX_DST)[i] = dst[i]; }
-    if ((rc = upload_idx(c, IX_DST, n))) return rc;
-    { Stage st(c, "k_cvt_u8", n * (1.0 * c->img.real_elems + Rb(c->img)));
-      launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W); }
-    enqueue_intermedium(c, n);
-    HIP_TRY(c, hipGetLastError());
-    for (int i = 0; i < n; ++i) c->slot_ready[dst[i]] = 3;
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, dst[i], false))) return rc;
+    const int nl = lanes_for(c, n);
+    for (int li = 0; li < nl; ++li) {
+        int b, e; chunk_of(n, nl, li, b, e);
+        const int m = e - b; if (m <= 0) continue;
+        Lane& L = c->lanes[li];
+        if ((rc = begin_call(c, L))) return rc;
+        for (int i = 0; i < m; ++i) { if ((rc = depend_for_write(c, L, li, dst[b + i]))) return rc; hidx(L, IX_DST)[i] = dst[b + i]; }
+        if ((rc = upload_idx(c, L, IX_DST, m))) return rc;
+        { Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
+          launch_cvt_u8(L.stream, m, d_gray + (size_t)b * c->img.real_elems, didx(L, IX_DST), c->arena_img, c->H, c->W); }
+        enqueue_intermedium(c, L, m);
+        HIP_TRY(c, hipGetLastError());
+        if ((rc = mark_written(c, L, li, dst + b, m)) || (rc = end_call(c, L))) return rc;
+    }
     return NIK_OK;
 }
 
@@ -523,34 +647,36 @@ int nik_intermedium_u8(nik_ctx* c, const uint8_t* gray, int stride, nik_frame ds
     if (!c || !gray) return fail(c, NIK_ERR_INVALID_ARG, "null argument");
     if (stride < c->W) return fail(c, NIK_ERR_INVALID_ARG, "stride %d smaller than width %d", stride, c->W);
     int rc;
-    if ((rc = drain_pending(c))) return rc;
-    HIP_TRY(c, hipMemcpy2DAsync(c->d_u8, c->W, gray, stride, c->W, c->H, hipMemcpyHostToDevice, c->stream));
+    if ((rc = drain_all(c))) return rc;                      // d_u8 staging is shared: one host image at a time
+    HIP_TRY(c, hipMemcpy2DAsync(c->d_u8, c->W, gray, stride, c->W, c->H, hipMemcpyHostToDevice, c->lanes[0].stream));
+    const int keep = c->active_lanes; c->active_lanes = 1;
     rc = nik_intermedium_batch_dev(c, 1, c->d_u8, &dst);
+    c->active_lanes = keep;
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return NIK_OK;
+    return drain_all(c);
 }
 
 int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {
     if (!c || !image) return fail(c, NIK_ERR_INVALID_ARG, "null argument");
     int rc;
-    if ((rc = drain_pending(c)) || (rc = begin_idx(c)) || (rc = check_slot(c, dst, false))) return rc;
+    if ((rc = drain_all(c)) || (rc = check_slot(c, dst, false))) return rc;
+    Lane& L = c->lanes[0];
+    if ((rc = begin_call(c, L)) || (rc = depend_for_write(c, L, 0, dst))) return rc;
     HIP_TRY(c, hipMemcpyAsync(c->arena_img + (size_t)dst * c->img.real_elems, image, sizeof(float) * c->img.real_elems,
-                              hipMemcpyHostToDevice, c->stream));
-    hidx(c, IX_DST)[0] = dst;
-    if ((rc = upload_idx(c, IX_DST, 1))) return rc;
-    enqueue_intermedium(c, 1);
+                              hipMemcpyHostToDevice, L.stream));
+    hidx(L, IX_DST)[0] = dst;
+    if ((rc = upload_idx(c, L, IX_DST, 1))) return rc;
+    enqueue_intermedium(c, L, 1);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->slot_ready[dst] = 3;
-    return NIK_OK;
+    if ((rc = mark_written(c, L, 0, &dst, 1)) || (rc = end_call(c, L))) return rc;
+    return drain_all(c);
 }
 
 int nik_frame_export(nik_ctx* c, nik_frame f, float* image, float* fft_result, float* fft_polar) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c)) || (rc = check_slot(c, f, true))) return rc;
-    hipStream_t s = c->stream;
+    if ((rc = nik_synchronize(c)) || (rc = check_slot(c, f, true))) return rc;
+    hipStream_t s = c->lanes[0].stream;
     if (image) HIP_TRY(c, hipMemcpyAsync(image, c->arena_img + (size_t)f * c->img.real_elems, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
     if (fft_result) {     // internal [hr][W] -> reference column-major (hr x W) == [W][hr]
@@ -569,8 +695,8 @@ int nik_frame_export(nik_ctx* c, nik_frame f, float* image, float* fft_result, f
 int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* fft_result, const float* fft_polar) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c)) || (rc = check_slot(c, f, false))) return rc;
-    hipStream_t s = c->stream;
+    if ((rc = nik_synchronize(c)) || (rc = check_slot(c, f, false))) return rc;
+    hipStream_t s = c->lanes[0].stream;
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
     if (image) { HIP_TRY(c, hipMemcpyAsync(c->arena_img + (size_t)f * c->img.real_elems, image, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s)); c->slot_ready[f] |= 1; }
     if (fft_result) {
@@ -583,7 +709,39 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
         launch_transpose_c(s, scratch, c->arena_P + (size_t)f * c->pol.spec_elems, c->PC, c->pol.g.hr);
     }
     HIP_TRY(c, hipStreamSynchronize(s));
+    c->slot_lane[f] = -1;                                   // host-synchronous write: visible to every lane
     if (fft_result && fft_polar) c->slot_ready[f] |= 2;
+    return NIK_OK;
+}
+
+// shared body of nik_pose_batch / nik_track_batch_dev
+static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* keys, const nik_frame* curs,
+                     int not_large_rotation, nik_pose_result* res) {
+    int rc;
+    const int nl = lanes_for(c, n);
+    for (int li = 0; li < nl; ++li) {
+        int b, e; chunk_of(n, nl, li, b, e);
+        const int m = e - b; if (m <= 0) continue;
+        Lane& L = c->lanes[li];
+        if ((rc = begin_call(c, L))) return rc;
+        for (int i = b; i < e; ++i) {
+            if ((rc = depend_on_slot(c, L, li, keys[i]))) return rc;
+            note_read(c, L, li, keys[i]);
+            if (d_gray) { if ((rc = depend_for_write(c, L, li, curs[i]))) return rc; }
+            else { if ((rc = depend_on_slot(c, L, li, curs[i]))) return rc; note_read(c, L, li, curs[i]); }
+        }
+        if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
+        if (d_gray) {
+            { Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
+              launch_cvt_u8(L.stream, m, d_gray + (size_t)b * c->img.real_elems, didx(L, IX_DST), c->arena_img, c->H, c->W); }
+            enqueue_intermedium(c, L, m);
+            if ((rc = mark_written(c, L, li, curs + b, m))) return rc;
+        }
+        if ((rc = enqueue_pose(c, L, m, not_large_rotation))) return rc;
+        HIP_TRY(c, hipGetLastError());
+        L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
+        if ((rc = end_call(c, L))) return rc;
+    }
     return NIK_OK;
 }
 
@@ -594,16 +752,9 @@ int nik_pose_batch(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* cu
     if ((rc = check_kernel(c))) return rc;
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
-    if ((rc = drain_pending(c)) || (rc = begin_idx(c))) return rc;
-    for (int i = 0; i < n; ++i) {
-        if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
-        hidx(c, IX_KEY)[i] = keys[i]; hidx(c, IX_CUR)[i] = curs[i];
-    }
-    if ((rc = upload_idx(c, IX_KEY, n)) || (rc = upload_idx(c, IX_CUR, n))) return rc;
-    if ((rc = enqueue_pose(c, n, not_large_rotation))) return rc;
-    HIP_TRY(c, hipGetLastError());
-    c->pending.active = true; c->pending.n = n; c->pending.n_hyp = not_large_rotation ? 1 : 2; c->pending.res = res;
-    return drain_pending(c);
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
+    if ((rc = pose_call(c, n, nullptr, keys, curs, not_large_rotation, res))) return rc;
+    return drain_all(c);
 }
 
 int nik_pose(nik_ctx* c, nik_frame key, nik_frame cur, int not_large_rotation, double pose[3], double info[3],
@@ -624,20 +775,9 @@ int nik_track_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const nik_fram
     if ((rc = check_kernel(c))) return rc;
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
-    if ((rc = drain_pending(c)) || (rc = begin_idx(c))) return rc;
-    for (int i = 0; i < n; ++i) {
-        if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, cur_dst[i], false))) return rc;
-        hidx(c, IX_KEY)[i] = keys[i]; hidx(c, IX_CUR)[i] = cur_dst[i]; hidx(c, IX_DST)[i] = cur_dst[i];
-    }
-    if ((rc = upload_idx(c, IX_KEY, n)) || (rc = upload_idx(c, IX_CUR, n)) || (rc = upload_idx(c, IX_DST, n))) return rc;
-    { Stage st(c, "k_cvt_u8", n * (1.0 * c->img.real_elems + Rb(c->img)));
-      launch_cvt_u8(c->stream, n, d_gray, didx(c, IX_DST), c->arena_img, c->H, c->W); }
-    enqueue_intermedium(c, n);
-    for (int i = 0; i < n; ++i) c->slot_ready[cur_dst[i]] = 3;
-    if ((rc = enqueue_pose(c, n, not_large_rotation))) return rc;
-    HIP_TRY(c, hipGetLastError());
-    c->pending.active = true; c->pending.n = n; c->pending.n_hyp = not_large_rotation ? 1 : 2; c->pending.res = res;
-    return sync ? drain_pending(c) : NIK_OK;
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, cur_dst[i], false))) return rc;
+    if ((rc = pose_call(c, n, d_gray, keys, cur_dst, not_large_rotation, res))) return rc;
+    return sync ? drain_all(c) : NIK_OK;
 }
 
 int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* best, nik_pose_result* res,
@@ -662,9 +802,8 @@ int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* b
 
 int nik_profile_enable(nik_ctx* c, int enable) {
     if (!c) return NIK_ERR_INVALID_ARG;
-    int rc = drain_pending(c);
+    int rc = nik_synchronize(c);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& r : c->prof_recs) { c->prof_pool.push_back(r.a); c->prof_pool.push_back(r.b); }
     c->prof_recs.clear(); c->prof_stats.clear();
     c->prof_on = enable != 0;
@@ -673,9 +812,8 @@ int nik_profile_enable(nik_ctx* c, int enable) {
 
 int nik_profile_read(nik_ctx* c, nik_stage_stat* out, int cap, int* n) {
     if (!c || !n) return NIK_ERR_INVALID_ARG;
-    int rc = drain_pending(c);
+    int rc = nik_synchronize(c);
     if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& r : c->prof_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) c->prof_stats[r.stage].ms += ms;
@@ -698,15 +836,15 @@ int nik_dbg_set_ablate(int flags) { set_ablate(flags); return NIK_OK; }
 int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     if (!c || !x || !xf_out) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c))) return rc;
+    if ((rc = nik_synchronize(c))) return rc;
     Family& f = which ? c->pol : c->img;
-    hipStream_t s = c->stream;
+    Lane& L = c->lanes[0]; hipStream_t s = L.stream;
     float* d_in = c->d_scratch;                                                   // first half: real input
     float2* d_out = reinterpret_cast<float2*>(c->d_scratch) + c->spec_max;        // second half: transposed output
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * f.real_elems, hipMemcpyHostToDevice, s));
-    launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, nullptr, c->tmpA, c->spec_max);
-    launch_B_fwd(s, 1, f.g, f.t, c->tmpA, c->spec_max, c->tmpA, c->spec_max, nullptr);
-    launch_transpose_c(s, c->tmpA, d_out, f.g.hr, f.g.cols);
+    launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, nullptr, L.tmpA, c->spec_max);
+    launch_B_fwd(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
+    launch_transpose_c(s, L.tmpA, d_out, f.g.hr, f.g.cols);
     HIP_TRY(c, hipMemcpyAsync(xf_out, d_out, sizeof(float2) * f.spec_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -716,15 +854,15 @@ int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
 int nik_dbg_ifft(nik_ctx* c, int which, const float* xf, float* x_out) {
     if (!c || !xf || !x_out) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c))) return rc;
+    if ((rc = nik_synchronize(c))) return rc;
     Family& f = which ? c->pol : c->img;
-    hipStream_t s = c->stream;
+    Lane& L = c->lanes[0]; hipStream_t s = L.stream;
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(scratch, xf, sizeof(float2) * f.spec_elems, hipMemcpyHostToDevice, s));
-    launch_transpose_c(s, scratch, c->tmpA, f.g.cols, f.g.hr);
-    launch_B_inv(s, 1, f.g, f.t, c->tmpA, c->spec_max, c->gbuf, c->spec_max);
-    float* dst = reinterpret_cast<float*>(c->kbuf);
-    launch_A_inv_real(s, 1, f.g, f.t, c->gbuf, c->spec_max, dst, f.real_elems);
+    launch_transpose_c(s, scratch, L.tmpA, f.g.cols, f.g.hr);
+    launch_B_inv(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.gbuf, c->spec_max);
+    float* dst = reinterpret_cast<float*>(L.kbuf);
+    launch_A_inv_real(s, 1, f.g, f.t, L.gbuf, c->spec_max, dst, f.real_elems);
     HIP_TRY(c, hipMemcpyAsync(x_out, dst, sizeof(float) * f.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -734,12 +872,12 @@ int nik_dbg_ifft(nik_ctx* c, int which, const float* xf, float* x_out) {
 int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     if (!c || !out) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c)) || (rc = check_slot(c, fr, false))) return rc;
+    if ((rc = nik_synchronize(c)) || (rc = check_slot(c, fr, false))) return rc;
     if (!(c->slot_ready[fr] & 1)) return fail(c, NIK_ERR_NOT_READY, "frame slot %d holds no image", fr);
-    hipStream_t s = c->stream;
+    Lane& L = c->lanes[0]; hipStream_t s = L.stream;
     std::vector<int> terms((size_t)2 * c->W + 2 * c->H);
     rotation_terms(c->H, c->W, (float)degree2 * 0.5f, terms.data());             // RotateArray(image, degree2/2)
-    int* d_terms = reinterpret_cast<int*>(c->gbuf);
+    int* d_terms = reinterpret_cast<int*>(L.gbuf);
     HIP_TRY(c, hipMemcpyAsync(d_terms, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
     launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img.real_elems, d_terms, c->d_scratch, c->H, c->W);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
@@ -751,14 +889,14 @@ int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
 int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     if (!c || !x || !out) return NIK_ERR_INVALID_ARG;
     int rc;
-    if ((rc = drain_pending(c))) return rc;
-    hipStream_t s = c->stream;
-    float* d_out = reinterpret_cast<float*>(c->gbuf);
+    if ((rc = nik_synchronize(c))) return rc;
+    Lane& L = c->lanes[0]; hipStream_t s = L.stream;
+    float* d_out = reinterpret_cast<float*>(L.gbuf);
     float* d_in = c->d_scratch;
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
-    launch_make_shifted(s, d_in, c->splane, c->H, c->W);
-    launch_fix_zero(s, 1, c->splane, c->s_elems, c->H, c->W);
-    launch_dbg_polar(s, c->splane, c->polar_tab, d_out, c->H, c->W, c->PD, c->PC);
+    launch_make_shifted(s, d_in, L.splane, c->H, c->W);
+    launch_fix_zero(s, 1, L.splane, c->s_elems, c->H, c->W);
+    launch_dbg_polar(s, L.splane, c->polar_tab, d_out, c->H, c->W, c->PD, c->PC);
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(float) * c->pol.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());

@@ -40,10 +40,13 @@ PlanDesc plan_desc(int n_) {
     return d;
 }
 
+#ifndef KCC_ALX
+#define KCC_ALX 16
+#endif
 int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT
 void set_ablate(int f) { g_ablate = f; }
 
-constexpr int A_LX = 16;     // lines per A-type workgroup (16 float2 = one 128-B segment per spectrum row)
+constexpr int A_LX = KCC_ALX;     // lines per A-type workgroup (16 float2 = one 128-B segment per spectrum row)
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -148,7 +151,7 @@ enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
 struct AArgs {
-    int rows, cols, hr, n_items;
+    int rows, cols, hr, n_items, ablate;
     const float2* tw_f; const float2* tw_i; const float2* tw_full;
     // forward source
     const float* src; size_t src_stride; const int* src_idx;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
     const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
-    a_load_pre<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
+    if (!(a.ablate & 1)) a_load_pre<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
     __syncthreads();
     float2 vin[1][DI::RF], vout[1][DI::RL];
     if (j < DI::MF) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
     }
     __syncthreads();                                         // natural buffer consumed before the exchange overwrites it
     float2* const ex[1] = { lds + line * C::EPITCH };
-    fft_chain<P, true, 1>(vin, vout, j, ex, a.tw_i);
+    if (!(a.ablate & 4)) fft_chain<P, true, 1>(vin, vout, j, ex, a.tw_i);
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
 
@@ -408,14 +411,14 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
             atomicMax(a.maxbuf + 2 * item + plane, __float_as_uint(m2));   // non-negative floats order as uints
         }
         float2 fout[1][DF::RL];
-        fft_chain<P, false, 1>(vout, fout, j, ex, a.tw_f);
+        if (!(a.ablate & 4)) fft_chain<P, false, 1>(vout, fout, j, ex, a.tw_f);
         __syncthreads();
         if (j < DF::ML) {
 #pragma unroll
             for (int q = 0; q < DF::RL; ++q) lds[line * C::NPITCH + j + q * DF::ML] = fout[0][q];
         }
         __syncthreads();
-        a_post_store<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
+        if (!(a.ablate & 2)) a_post_store<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
     } else {
         // arg-max (column-major first strict max, Eigen maxCoeff visitor) + moments for GetInfo
         float best = -INFINITY; int bidx = 0x7FFFFFFF;
@@ -465,7 +468,7 @@ template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items,
 
 static AArgs base_args(PlaneGeom g, Tables t) {
     AArgs a{};
-    a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full;
+    a.ablate = g_ablate; a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full;
     return a;
 }
 
