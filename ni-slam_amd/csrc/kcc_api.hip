@@ -33,7 +33,7 @@ struct Family {                 // one plane geometry with its tables
 };
 
 // index arrays of one call (each cap_items ints)
-enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_PAIR = 3, IX_VARIANT = 4, IX_TIMG = 5, IX_TKEY = 6, IX_ROTIDX = 7, IX_COUNT = 8 };
+enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_TIMG = 3, IX_TKEY = 4, IX_ROTIDX = 5, IX_COUNT = 6 };
 
 struct Call {                   // one in-flight call on a lane
     int* h_idx = nullptr;                                   // pinned staging, IX_COUNT * cap_items
@@ -80,7 +80,7 @@ struct nik_ctx {
     std::vector<int8_t> slot_lane;       // lane that last wrote the slot (-1: none / host import)
     std::vector<unsigned long> slot_seq; // that lane's write_seq at the time
     std::vector<unsigned long> slot_rd;  // [slot][4]: call_seq of each lane's latest call that read the slot
-    size_t s_elems = 0, spec_max = 0; int partial_stride = 0;
+    size_t s_elems = 0, spec_max = 0, r_elems = 0; int partial_stride = 0;
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     float* d_scratch = nullptr;          // debug / import-export staging
@@ -409,22 +409,20 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n) {
       launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems); }
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
     { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
-      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab,
-                         L.tmpA, c->spec_max); }
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab, L.tmpA, c->spec_max); }
     { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
 }
 
 // EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
 void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const float2* xsrc, size_t x_stride, const int* x_idx,
-                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out) {
+                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out, int* rot_index, int n_hyp) {
     hipStream_t s = L.stream;
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
-    (void)hipMemsetAsync(L.maxbuf, 0, sizeof(unsigned) * 2 * n, s);
     if (c->cfg.kernel == 1 && !x_fwd)
         launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
     { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
-      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride); }
+      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf); }
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
       launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy); }
     { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
@@ -432,7 +430,7 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     const int nb = argmax_blocks(f.g);
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
       launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
-    launch_finalize(s, n, L.partials, c->partial_stride, nb, out);
+    launch_finalize(s, n, L.partials, c->partial_stride, nb, out, rot_index, n_hyp, c->PD);
 }
 
 // ComputePose (correlation_flow.cc:97-143) for n pairs; key/cur slots in the lane's IX_KEY / IX_CUR arrays.
@@ -442,9 +440,8 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation) {
     const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
     // rotation stage: z = key polar spectrum, x = current polar spectrum
     enqueue_estimate(c, L, n, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
-                     c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res);
+                     c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
-    launch_rot_index(s, nt, L.rot_res, didx(L, IX_PAIR), didx(L, IX_VARIANT), c->PD, didx(L, IX_ROTIDX));
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
     { Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
       launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(L, IX_TIMG), c->rot_tab,
@@ -453,10 +450,10 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation) {
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
         launch_B_fwd(s, nt, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
         enqueue_estimate(c, L, nt, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(L, IX_TKEY), L.trans_res);
+                         didx(L, IX_TKEY), L.trans_res, nullptr, 1);
     } else {
         enqueue_estimate(c, L, nt, c->img, true, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(L, IX_TKEY), L.trans_res);
+                         didx(L, IX_TKEY), L.trans_res, nullptr, 1);
     }
     HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(L.cur->h_trans, L.trans_res, sizeof(SurfaceResult) * nt, hipMemcpyDeviceToHost, s));
@@ -470,8 +467,7 @@ int stage_pose_indices(nik_ctx* c, Lane& L, int n, const nik_frame* keys, const 
     for (int i = 0; i < n; ++i) { hidx(L, IX_KEY)[i] = keys[i]; hidx(L, IX_CUR)[i] = curs[i]; if (with_dst) hidx(L, IX_DST)[i] = curs[i]; }
     for (int t = 0; t < nt; ++t) {
         const int p = t / n_hyp, hyp = t % n_hyp;
-        hidx(L, IX_PAIR)[t] = p;
-        hidx(L, IX_VARIANT)[t] = not_large_rotation ? 0 : 1 + hyp;
+        (void)hyp;
         hidx(L, IX_TIMG)[t] = curs[p];
         hidx(L, IX_TKEY)[t] = keys[p];
     }
@@ -565,6 +561,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if ((rc = family_init(c, c->img, H, W)) || (rc = family_init(c, c->pol, PD, PC))) return bail(rc);
     c->spec_max = std::max(c->img.spec_elems, c->pol.spec_elems);
     c->s_elems = (size_t)(W + 1) * (H + 2);
+    c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
     c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
     TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img.real_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));

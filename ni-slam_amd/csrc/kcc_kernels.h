@@ -104,7 +104,7 @@ void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
-                      float2* out, size_t item_stride, size_t plane_stride);
+                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero);
 // G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride);
@@ -113,12 +113,10 @@ void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, size_t x_stride, const int* x_idx,
                    const float2* zsrc, size_t z_stride, const int* z_idx, float* energy);
 
-// reduce partials -> SurfaceResult per item
+// reduce partials -> SurfaceResult per item; rot_index (optional): de-rotation table index of the n_hyp
+// translation items of each pair, variant(h) * PD + arg-max row
 void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials,
-                     SurfaceResult* out);
-// rot_index[t] = variant[t] * PD + (res[pair[t]].idx % PD)   (row of the rotation arg-max selects the angle)
-void launch_rot_index(hipStream_t s, int n_items, const SurfaceResult* rot_res, const int* pair, const int* variant,
-                      int PD, int* rot_index);
+                     SurfaceResult* out, int* rot_index, int n_hyp, int PD);
 
 // debug: the two gathers on their own (no FFT)
 void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W);

@@ -40,6 +40,9 @@ PlanDesc plan_desc(int n_) {
     return d;
 }
 
+#ifndef KCC_GATHER_GROUP
+#define KCC_GATHER_GROUP 4
+#endif
 #ifndef KCC_ALX
 #define KCC_ALX 16
 #endif
@@ -174,33 +177,42 @@ template <int HH> struct ACfg {
     static constexpr int NPITCH = HH + 1;                // natural-order pitch: odd -> conflict-free transposes
     static constexpr int LDS_ELEMS = A_LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
     static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
+    // waves per SIMD the LDS footprint allows: ask the register allocator to fit that occupancy
+    static constexpr int BLOCKS = (int)(160 * 1024 / BYTES) > 8 ? 8 : (int)(160 * 1024 / BYTES);
+    static constexpr int WPS_ = (BLOCKS * ((NT + 63) / 64) + 3) / 4;
+    static constexpr int WPS = WPS_ > 8 ? 8 : (WPS_ < 1 ? 1 : WPS_);
 };
 
-// cv::borderInterpolate(BORDER_WRAP) for coordinates at most one period outside (the common case for a
-// rotation about the centre); anything further falls back to the general formula.
-__device__ __forceinline__ int wrap1(int p, int len) {
-    p += (p < 0) ? len : 0;
-    p -= (p >= len) ? len : 0;
-    if (__builtin_expect((unsigned)p >= (unsigned)len, 0)) p = wrap_idx(p, len);
-    return p;
+// 8-byte load from a 4-byte aligned address (two vertically adjacent taps)
+__device__ __forceinline__ float2 load2(const float* p) {
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+    const f2u v = *reinterpret_cast<const f2u*>(p);
+    return make_float2(v.x, v.y);
 }
 // RotateArray (utils.cc:154-161): cv::warpAffine(INTER_LINEAR, BORDER_WRAP).  The fixed-point coordinate
 // terms of OpenCV's WarpAffineInvoker (adelta[c], bdelta[c], X0[r], Y0[r]) are tabulated per candidate angle on
-// the host, so the device does integer adds only.  Returns dst pixel (r, c).
+// the host, so the device does integer adds only.  nik_create() restricts the aspect ratio so that a rotation
+// about the centre keeps every source coordinate within one period: BORDER_WRAP is a single conditional add
+// (identical to cv::borderInterpolate there), and saturate_cast<short> can never clip.  Returns dst pixel (r, c).
 __device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H, int W, int ad, int bd, int X0, int Y0) {
     const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
-    int sx = X >> 5, sy = Y >> 5;
-    sx = max(-32768, min(32767, sx)); sy = max(-32768, min(32767, sy));
-    const int xa = wrap1(sx, W), xb = wrap1(sx + 1, W);
-    const int ya = wrap1(sy, H), yb = wrap1(sy + 1, H);
-    const float* ca = img + (size_t)xa * H; const float* cb = img + (size_t)xb * H;
-    return bilerp(ca[ya], cb[ya], ca[yb], cb[yb], X & 31, Y & 31);
+    int xa = X >> 5, ya = Y >> 5;
+    xa += (xa < 0) ? W : 0; xa -= (xa >= W) ? W : 0;
+    ya += (ya < 0) ? H : 0; ya -= (ya >= H) ? H : 0;
+    const int xb = (xa + 1 == W) ? 0 : xa + 1, yb = (ya + 1 == H) ? 0 : ya + 1;
+    // the two taps of a column are adjacent in memory (rows are contiguous): one 8-byte load each, fixed up in the
+    // rare wrap case ya == H-1 (yb == 0)
+    const float* ca = img + (unsigned)(xa * H); const float* cb = img + (unsigned)(xb * H);
+    float2 va = load2(ca + ya), vb = load2(cb + ya);
+    if (yb == 0) { va.y = ca[0]; vb.y = cb[0]; }
+    return bilerp(va.x, vb.x, va.y, vb.y, X & 31, Y & 31);
 }
 // polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven cv::remap sample from
 // the shifted, zero-bordered plane S (column pitch SP).  Table entry: offset(sx*SP+sy):22 | fx:5 | fy:5.
 __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int SP, uint32_t t) {
     const float* q = S + (t & 0x3FFFFF);
-    return bilerp(q[0], q[SP], q[1], q[SP + 1], (t >> 22) & 31, t >> 27);
+    const float2 va = load2(q), vb = load2(q + SP);                 // (sx, sy..sy+1), (sx+1, sy..sy+1)
+    return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
@@ -278,8 +290,11 @@ __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict
     }
 }
 
+#ifndef KCC_ROT_WPS
+#define KCC_ROT_WPS 1
+#endif
 template <int HH, int SRC>
-__global__ __launch_bounds__(ACfg<HH>::NT) void kA_fwd(AArgs a) {
+__global__ __launch_bounds__(ACfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : ACfg<HH>::WPS)) void kA_fwd(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = ACfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     float2* lds = reinterpret_cast<float2*>(smem);
@@ -296,28 +311,59 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_fwd(AArgs a) {
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
         } else if (SRC == SRC_ROT) {
+            // (handled below: needs the whole workgroup for the LDS staging of the angle's X0/Y0 terms)
+        } else {
+            // (polar: handled below with a patch-shaped lane mapping)
+        }
+    }
+    if (SRC == SRC_POLAR) {
+        // polar(fftshift(RemoveZeroComponent(p))): lanes = 16 radii x 4 angle pairs, i.e. a compact ~8 x 17 px patch
+        // of the source per wave-instruction (an arc of 64 angles would touch a different cache line per lane).
+        // Samples go to LDS in natural order, then every thread picks up its first-pass points.
+        const float* S = a.src + (size_t)item * a.src_stride;
+        const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab + (size_t)x0 * a.rows);
+        constexpr int TOT = A_LX * HH, ITERS = (TOT + C::NT - 1) / C::NT;
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int idx = tid + it * C::NT;
+            if (idx < TOT) {
+                const int ln = idx % A_LX, m = idx / A_LX;
+                const uint2 t = tab[(size_t)ln * HH + m];
+                lds[ln * C::NPITCH + m] = make_float2(polar_sample(S, a.SP, t.x), polar_sample(S, a.SP, t.y));
+            }
+            if ((it % KCC_GATHER_GROUP) == KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        if (j < D::MF) {
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) vin[0][q] = lds[line * C::NPITCH + j + q * D::MF];
+        }
+        __syncthreads();                                     // natural buffer consumed before the exchange overwrites it
+    }
+    if (SRC == SRC_ROT) {
+        // stage this angle's row terms X0[r], Y0[r] (2H ints) in LDS: the gather then has ONE dependent global
+        // stage (the taps) instead of two (table, then taps)
+        const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
+        int* xy = reinterpret_cast<int*>(lds);               // [X0 H | Y0 H], overwritten by the exchange afterwards
+        for (int i = tid; i < 2 * a.rows; i += C::NT) xy[i] = tab[2 * a.cols + i];
+        const int c = x0 + line;
+        const int ad = tab[c], bd = tab[a.cols + c];
+        __syncthreads();
+        if (j < D::MF) {
             const float* img = a.src + (size_t)a.src_idx[item] * a.src_stride;
-            const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
-            const int c = x0 + line;
-            const int ad = tab[c], bd = tab[a.cols + c];
-            const int2* X0 = reinterpret_cast<const int2*>(tab + 2 * a.cols);
-            const int2* Y0 = reinterpret_cast<const int2*>(tab + 2 * a.cols + a.rows);
+            const int2* X0 = reinterpret_cast<const int2*>(xy);
+            const int2* Y0 = reinterpret_cast<const int2*>(xy + a.rows);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) {
                 const int m = j + q * D::MF;
                 const int2 xr = X0[m], yr = Y0[m];
                 vin[0][q] = make_float2(rot_sample(img, a.rows, a.cols, ad, bd, xr.x, yr.x),
                                         rot_sample(img, a.rows, a.cols, ad, bd, xr.y, yr.y));
-            }
-        } else {
-            const float* S = a.src + (size_t)item * a.src_stride;
-            const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab + (size_t)(x0 + line) * a.rows);
-#pragma unroll
-            for (int q = 0; q < D::RF; ++q) {
-                const uint2 t = tab[j + q * D::MF];
-                vin[0][q] = make_float2(polar_sample(S, a.SP, t.x), polar_sample(S, a.SP, t.y));
+                // cap the number of gathers in flight (register pressure -> occupancy): no hoisting across groups
+                if ((q % KCC_GATHER_GROUP) == KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
             }
         }
+        __syncthreads();                                     // table consumed before the exchange buffer is written
     }
     float2* const ex[1] = { lds + line * C::EPITCH };
     fft_chain<P, false, 1>(vin, vout, j, ex, a.tw_f);
@@ -331,7 +377,7 @@ __global__ __launch_bounds__(ACfg<HH>::NT) void kA_fwd(AArgs a) {
 }
 
 template <int HH, int EPI>
-__global__ __launch_bounds__(ACfg<HH>::NT) void kA_inv(AArgs a) {
+__global__ __launch_bounds__(ACfg<HH>::NT, ACfg<HH>::WPS) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = ACfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr int NW = (C::NT + 63) / 64;
@@ -565,6 +611,7 @@ struct BArgs {
     float2* dst2; size_t dst2_stride;                             // secondary output
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; float lambda;
+    unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
 };
 
 template <int N> struct BCfg {
@@ -635,6 +682,7 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
     } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
         // xzf = xf * zf.conjugate() for (z,z) and (x,z)   (correlation_flow.cc:210-211,220-221)
         float2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
+        if (blockIdx.x == 0 && tid < 2) a.maxbuf_zero[2 * item + tid] = 0u;    // consumed by the following kernel_fwd launch
         // the key spectrum line is needed only after the forward chain: issue its loads first (latency hidden)
         load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
         if (MODE == B_FWD_MUL_INV) {
@@ -739,8 +787,9 @@ void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
-                      float2* out, size_t item_stride, size_t plane_stride) {
+                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero) {
     BArgs a = base_bargs(g, t);
+    a.maxbuf_zero = maxbuf_zero;
     a.src = xsrc; a.src_stride = x_stride; a.src_idx = x_idx; a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx;
     a.dst = out; a.dst_stride = item_stride; a.out_plane_stride = plane_stride;
     if (x_fwd) {
@@ -785,27 +834,26 @@ void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, 
                        (size_t)g.hr * g.cols, energy);
 }
 
-__global__ void k_finalize(const Partial* __restrict__ partials, int partial_stride, int n_partials, SurfaceResult* out) {
+// reduce the per-workgroup partials of one response surface (fixed order -> deterministic); for the rotation
+// surface also emit the de-rotation table index of every translation item of the pair:
+//   rot_index[item*n_hyp + h] = variant(h) * PD + arg-max row       (variant 0: small-rotation fold, 1/2: orig / +180)
+__global__ void k_finalize(const Partial* __restrict__ partials, int partial_stride, int n_partials, SurfaceResult* out,
+                           int* rot_index, int n_hyp, int PD) {
     const int item = blockIdx.x;
     if (threadIdx.x != 0) return;
     const Partial* p = partials + (size_t)item * partial_stride;
     SurfaceResult r; r.sum = 0; r.sumsq = 0; r.peak = -INFINITY; r.idx = 0x7FFFFFFF;
-    for (int i = 0; i < n_partials; ++i) {           // fixed order -> deterministic
+    for (int i = 0; i < n_partials; ++i) {
         r.sum += p[i].sum; r.sumsq += p[i].sumsq;
         if (p[i].peak > r.peak || (p[i].peak == r.peak && p[i].idx < r.idx)) { r.peak = p[i].peak; r.idx = p[i].idx; }
     }
     out[item] = r;
+    if (rot_index)
+        for (int h = 0; h < n_hyp; ++h) rot_index[item * n_hyp + h] = (n_hyp == 1 ? 0 : 1 + h) * PD + (r.idx % PD);
 }
-void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials, SurfaceResult* out) {
-    hipLaunchKernelGGL(k_finalize, dim3(n_items), dim3(64), 0, s, partials, partial_stride, n_partials, out);
-}
-
-__global__ void k_rot_index(int n_items, const SurfaceResult* rot_res, const int* pair, const int* variant, int PD, int* rot_index) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_items) rot_index[t] = variant[t] * PD + (rot_res[pair[t]].idx % PD);
-}
-void launch_rot_index(hipStream_t s, int n_items, const SurfaceResult* rot_res, const int* pair, const int* variant, int PD, int* rot_index) {
-    hipLaunchKernelGGL(k_rot_index, dim3((n_items + 63) / 64), dim3(64), 0, s, n_items, rot_res, pair, variant, PD, rot_index);
+void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials, SurfaceResult* out,
+                     int* rot_index, int n_hyp, int PD) {
+    hipLaunchKernelGGL(k_finalize, dim3(n_items), dim3(64), 0, s, partials, partial_stride, n_partials, out, rot_index, n_hyp, PD);
 }
 
 // RemoveZeroComponent (correlation_flow.cc:79-87) on the shifted plane S: p(r,c) lives at S[(c+W/2)%W][(r+H/2)%H].
