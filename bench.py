@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=128, help="frame pairs per GPU per step")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated (tiled to --batch)")
-    ap.add_argument("--cpu-sample", type=int, default=16, help="pairs timed on the host for cpu_baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     args = ap.parse_args()
 
@@ -40,8 +40,9 @@ def main():
     import torch
     import torch.distributed as dist
     import synth
-    from kcc_helpers import check_pose_parity, nik
+    from kcc_helpers import PKG, check_pose_parity, load_module, nik
     N = nik()
+    kd = load_module("kcc_dist", os.path.join(PKG, "kcc_dist.py"))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -81,12 +82,8 @@ def main():
         k = state["k"]
         res = cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=False, res=ring[k % 3])
         if world > 1 and k >= 2:
-            old = ring[(k - 2) % 3]
-            s = np.zeros(4)
-            for r in old:
-                s += (r.info[0], r.info[2], r.pose[0] ** 2 + r.pose[1] ** 2, 1.0)
-            stats.copy_(torch.from_numpy(s), non_blocking=True)
-            dist.all_reduce(stats)                                   # RCCL: [sum PSR_t, sum PSR_r, sum |t|^2, count]
+            stats.copy_(kd.residual_stats(ring[(k - 2) % 3]), non_blocking=True)
+            kd.allreduce_residual_stats(stats)                       # RCCL: [sum PSR_t, sum PSR_r, sum |t|^2, count]
         state["k"] = k + 1
         return res
 
@@ -133,8 +130,18 @@ def main():
                                     bytes_per_launch=bpl, gbps=round(bpl / (avg_ms * 1e-3) / 1e9, 1)))
             top = kernels[0]
             ach = top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9
+            # measured HBM bytes of that kernel per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
+            # DESIGN.md section 4 describes; committed summary) -- only valid for the batch size it was collected at
+            traffic = None
+            try:
+                import glob
+                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
+                if pm.get("pairs_per_launch") == B:
+                    traffic = pm["traffic_bytes_per_launch"].get(top["name"])
+            except Exception:
+                traffic = None
             roof = dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=None, avg_ms=top["avg_ms"],
+                        frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=traffic, avg_ms=top["avg_ms"],
                         bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
         # ---- parity spot check of the last step against the oracle (not timed)
         from oracle import kcc_oracle as ko
@@ -150,7 +157,7 @@ def main():
             reps_c = (ns + U - 1) // U
             kk, cc = np.tile(keys_u8, (reps_c, 1, 1))[:ns], np.tile(curs_u8, (reps_c, 1, 1))[:ns]
             _, _, _, secs_all = ko.track_pairs(ocfg, kk, cc, True, faithful=False, nthreads=min(ncores, ns))
-            n1 = max(1, min(4, ns))
+            n1 = max(1, min(8, ns))
             _, _, _, secs_1 = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=False, nthreads=1)
             _, _, _, secs_1f = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=True, nthreads=1)
             cpu = dict(value=round(ns / secs_all, 2), unit="frame-pairs/s", cores=min(ncores, ns), kind="port",

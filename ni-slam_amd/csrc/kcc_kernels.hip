@@ -49,7 +49,12 @@ PlanDesc plan_desc(int n_) {
 int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT
 void set_ablate(int f) { g_ablate = f; }
 
-constexpr int A_LX = KCC_ALX;     // lines per A-type workgroup (16 float2 = one 128-B segment per spectrum row)
+// lines per A-type workgroup: 16 float2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
+// use 8 so that twice as many independent workgroups fit in a CU's LDS (their phases overlap better)
+#ifndef KCC_ALX360
+#define KCC_ALX360 8
+#endif
+__host__ __device__ constexpr int a_lx(int hh) { return hh >= 360 ? KCC_ALX360 : KCC_ALX; }
 
 // ------------------------------------------------------------------------------------------------
 // small helpers
@@ -168,14 +173,16 @@ struct AArgs {
     KernelFn fn; unsigned* maxbuf; const float* energy;
 };
 
-template <int HH> struct ACfg {
+template <int HH, int LXV> struct ACfg {
+    static constexpr int HALF = HH;
     using P = PlanFor<HH>;
     static constexpr int T = P::T;                       // threads per line
-    static constexpr int NT = A_LX * T;
+    static constexpr int LX = LXV;
+    static constexpr int NT = LX * T;
     // exchange pitch: >= EXT and == T (mod 32) so the lines sharing a wave-instruction use disjoint banks
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
     static constexpr int NPITCH = HH + 1;                // natural-order pitch: odd -> conflict-free transposes
-    static constexpr int LDS_ELEMS = A_LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
+    static constexpr int LDS_ELEMS = LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
     static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
     // waves per SIMD the LDS footprint allows: ask the register allocator to fit that occupancy
     static constexpr int BLOCKS = (int)(160 * 1024 / BYTES) > 8 ? 8 : (int)(160 * 1024 / BYTES);
@@ -215,12 +222,16 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int S
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
+template <int HH> using FCfg = ACfg<HH, KCC_ALX>;            // forward (real -> spectrum) kernels
+template <int HH> using ICfg = ACfg<HH, a_lx(HH)>;           // inverse (spectrum -> ...) kernels
+
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
-template <int HH>
+template <class C>
 __device__ __forceinline__ void a_post_store(const float2* nat, const float2* __restrict__ tw_full,
                                              float2* __restrict__ spec, int cols, int x0, int tid) {
-    constexpr int NPITCH = ACfg<HH>::NPITCH, NT = ACfg<HH>::NT, NP = HH / 2 + 1;
+    constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
+    constexpr int A_LX = C::LX;
     constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
     float2 va[ITERS], vb[ITERS], w[ITERS];
 #pragma unroll
@@ -254,10 +265,11 @@ __device__ __forceinline__ void a_post_store(const float2* nat, const float2* __
 }
 // transposed global load (k-major spectrum) -> c2r merge -> natural-order input of the packed inverse FFT in LDS.
 // All global loads of a thread are issued before the arithmetic.
-template <int HH>
+template <class C>
 __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict__ tw_full,
                                            const float2* __restrict__ spec, int cols, int x0, int tid) {
-    constexpr int NPITCH = ACfg<HH>::NPITCH, NT = ACfg<HH>::NT, NP = HH / 2 + 1;
+    constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
+    constexpr int A_LX = C::LX;
     constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
     float2 va[ITERS], vb[ITERS], w[ITERS];
 #pragma unroll
@@ -294,12 +306,13 @@ __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict
 #define KCC_ROT_WPS 1
 #endif
 template <int HH, int SRC>
-__global__ __launch_bounds__(ACfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : ACfg<HH>::WPS)) void kA_fwd(AArgs a) {
+__global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<HH>::WPS)) void kA_fwd(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = ACfg<HH>; using P = typename C::P; using D = Dir<P, false>;
+    using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     float2* lds = reinterpret_cast<float2*>(smem);
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
     int bx, item;
+    constexpr int A_LX = C::LX;
     xcd_coords(a.cols / A_LX, a.n_items, bx, item);
     const int x0 = bx * A_LX;
 
@@ -373,19 +386,20 @@ __global__ __launch_bounds__(ACfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : ACfg<
         for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
     }
     __syncthreads();
-    a_post_store<HH>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+    a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
 }
 
 template <int HH, int EPI>
-__global__ __launch_bounds__(ACfg<HH>::NT, ACfg<HH>::WPS) void kA_inv(AArgs a) {
+__global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = ACfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
+    using C = ICfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
     __shared__ float red_f[NW];
     __shared__ int red_i[NW];
     __shared__ double red_d[2][NW];
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
+    constexpr int A_LX = C::LX;
     const int nbx = a.cols / A_LX;
     int bx, item2;
     constexpr bool KFWD = epi_is_kfwd(EPI);
@@ -396,7 +410,7 @@ __global__ __launch_bounds__(ACfg<HH>::NT, ACfg<HH>::WPS) void kA_inv(AArgs a) {
     const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
-    if (!(a.ablate & 1)) a_load_pre<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
+    if (!(a.ablate & 1)) a_load_pre<C>(lds, a.tw_full, spec, a.cols, x0, tid);
     __syncthreads();
     float2 vin[1][DI::RF], vout[1][DI::RL];
     if (j < DI::MF) {
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(ACfg<HH>::NT, ACfg<HH>::WPS) void kA_inv(AArgs a) {
             for (int q = 0; q < DF::RL; ++q) lds[line * C::NPITCH + j + q * DF::ML] = fout[0][q];
         }
         __syncthreads();
-        if (!(a.ablate & 2)) a_post_store<HH>(lds, a.tw_full, spec, a.cols, x0, tid);
+        if (!(a.ablate & 2)) a_post_store<C>(lds, a.tw_full, spec, a.cols, x0, tid);
     } else {
         // arg-max (column-major first strict max, Eigen maxCoeff visitor) + moments for GetInfo
         float best = -INFINITY; int bidx = 0x7FFFFFFF;
@@ -499,17 +513,17 @@ __global__ __launch_bounds__(ACfg<HH>::NT, ACfg<HH>::WPS) void kA_inv(AArgs a) {
     }
 }
 
-int argmax_blocks(PlaneGeom g) { return g.cols / A_LX; }
+int argmax_blocks(PlaneGeom g) { return g.cols / a_lx(g.rows / 2); }
 
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
     a.n_items = n_items;
-    dim3 grid((a.cols / A_LX) * n_items), block(ACfg<HH>::NT);
-    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, ACfg<HH>::BYTES, s, a);
+    dim3 grid((a.cols / FCfg<HH>::LX) * n_items), block(FCfg<HH>::NT);
+    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, FCfg<HH>::BYTES, s, a);
 }
 template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
     a.n_items = n_items;
-    dim3 grid((a.cols / A_LX) * n_items * nz), block(ACfg<HH>::NT);
-    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ACfg<HH>::BYTES, s, a);
+    dim3 grid((a.cols / ICfg<HH>::LX) * n_items * nz), block(ICfg<HH>::NT);
+    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ICfg<HH>::BYTES, s, a);
 }
 
 static AArgs base_args(PlaneGeom g, Tables t) {
