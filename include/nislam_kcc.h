@@ -134,6 +134,44 @@ int nik_track_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_fr
 int nik_match(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands,
               int* best, nik_pose_result* res /* n entries, may be NULL */, nik_pose_result* best_res);
 
+/* ---- sequence driver: the tracking subset of MapBuilder ---------------- */
+
+/* Camera intrinsics after undistortion (reference Camera::_new_K, _height, _extrinsics; src/camera.cc:20-75)
+ * and KeyframeSelectionConfig (include/read_configs.h:27-32).  Undistortion itself (cv::remap) is not done
+ * here: frames are expected undistorted. */
+typedef struct {
+    double fx, fy, cx, cy;
+    double height;                 /* camera height above the ground plane */
+    double extrinsics[9];          /* row-major 3x3, applied to (x, y, theta) as the reference does (camera.cc:207) */
+    double max_distance, max_angle, lower_response_thr, upper_response_thr;
+} nik_tracker_config;
+
+typedef struct nik_tracker nik_tracker;
+
+typedef struct {
+    int32_t frame_id;              /* MapBuilder::_frame_id of this input                                     */
+    int32_t inserted;              /* AddNewInput's return value: the frame became a keyframe                 */
+    int32_t good_tracking;         /* Tracking(): PSR_t and PSR_r above lower_response_thr                    */
+    int32_t key_frame_id;          /* frame id of the keyframe this frame was registered against (-1: first)  */
+    nik_frame slot;                /* device slot holding the frame's spectra if it was inserted, else -1     */
+    double  response[3];           /* ComputePose's return value                                              */
+    double  cf_pose[3];            /* _current_cf_pose (image plane, pixels)                                  */
+    double  robot_pose[3];         /* _current_pose                                                           */
+} nik_track_output;
+
+/* replaces MapBuilder::MapBuilder's tracking members (map_builder.cc:18-28); the tracker borrows ctx */
+int  nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker** out);
+void nik_tracker_destroy(nik_tracker* t);
+/* replaces MapBuilder::AddNewInput (map_builder.cc:30-70) minus undistortion / map / loop closure, for n
+ * consecutive frames already in HBM (u8, [n][H][W]).  Frames are registered speculatively against the current
+ * keyframe in one batch and re-registered after every keyframe switch, so the outputs are exactly those of n
+ * sequential calls.  n <= max_batch of the context. */
+int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out);
+/* one host frame (cv::Mat CV_8UC1) */
+int  nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out);
+/* number of keyframes inserted so far and their slots (for loop closure: nik_match over these) */
+int  nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on nik_stream() around every hot-path launch.

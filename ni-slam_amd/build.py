@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnislam_kcc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-UNITS = [("kcc_kernels.hip", []), ("kcc_api.hip", ["-ffp-contract=off"])]
+UNITS = [("kcc_kernels.hip", []), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"])]
 HEADERS = ["kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
 
 
@@ -26,7 +26,7 @@ def build(force=False, verbose=False, defs=(), suffix=""):
     lib = LIB.replace(".so", suffix + ".so")
     for src, extra in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
+        o = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
         if force or _stale(o, [s] + hdrs):
             cmd = [HIPCC] + COMMON + extra + list(defs) + ["-c", s, "-o", o]
             if verbose:

@@ -1,0 +1,209 @@
+// kcc_tracker.cpp -- host-side sequence driver: the tracking subset of the reference's MapBuilder
+// (src/map_builder.cc:30-70,86-138,158-166), SE(2) chaining (src/utils.cc:134-152) and the camera pose
+// conversions (src/camera.cc:148-211), in double precision exactly as the reference, on top of the C ABI.
+// No GPU code here; every registration goes through nik_track_batch_dev / nik_pose_batch.
+#include "../../include/nislam_kcc.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct V3 { double v[3]; double& operator[](int i) { return v[i]; } double operator[](int i) const { return v[i]; } };
+
+// ceres::optimization_2d::NormalizeAngle (include/optimization_2d/normalize_angle.h:41-47)
+inline double normalize_angle(double a) { const double two_pi = 2.0 * M_PI; return a - two_pi * std::floor((a + M_PI) / two_pi); }
+
+// ComputeAbsolutePose (src/utils.cc:144-152) with RotationMatrix2D (pose_graph_2d_error_term.h:43-51)
+inline V3 compute_absolute_pose(const V3& p1, const V3& rel) {
+    const double c = std::cos(p1[2]), s = std::sin(p1[2]);
+    V3 r;
+    r[0] = p1[0] + (c * rel[0] - s * rel[1]);
+    r[1] = p1[1] + (s * rel[0] + c * rel[1]);
+    r[2] = normalize_angle(p1[2] + rel[2]);
+    return r;
+}
+// ComputeRelativePose (src/utils.cc:134-142)
+inline V3 compute_relative_pose(const V3& p1, const V3& p2) {
+    const double c = std::cos(p1[2]), s = std::sin(p1[2]);
+    const double dx = p2[0] - p1[0], dy = p2[1] - p1[1];
+    V3 r;
+    r[0] = c * dx + s * dy;          // Rw1^T * d
+    r[1] = -s * dx + c * dy;
+    r[2] = normalize_angle(p2[2] - p1[2]);
+    return r;
+}
+
+}  // namespace
+
+struct nik_tracker {
+    nik_ctx* ctx = nullptr;
+    nik_tracker_config cfg{};
+    int H = 0, W = 0, max_batch = 0, max_frames = 0;
+    bool init = false;
+    int frame_id = 0;
+    double distance = 0;
+    nik_frame key_slot = -1; int key_frame_id = -1;
+    V3 last_cf_pose{}, last_cf_real_pose{}, last_pose{};
+    std::vector<nik_frame> free_slots;
+    std::vector<nik_frame> keyframes;
+
+    // Camera::ConvertCenterToPrincipal (src/camera.cc:148-158)
+    V3 center_to_principal(const V3& c) const {
+        const double cs = std::cos(c[2]), sn = std::sin(c[2]);
+        const double bx = W * 0.5 - cfg.cx, by = H * 0.5 - cfg.cy;
+        // (I - R) * O_bias, R = [[cs,-sn],[sn,cs]]
+        V3 r;
+        r[0] = c[0] + ((1 - cs) * bx + sn * by);
+        r[1] = c[1] + (-sn * bx + (1 - cs) * by);
+        r[2] = c[2];
+        return r;
+    }
+    // Camera::ConvertImagePlanePoseToCamera (:160-176)
+    V3 image_plane_to_camera(const V3& p) const { V3 r; r[0] = p[0] / cfg.fx; r[1] = p[1] / cfg.fy; r[2] = p[2]; return r; }
+    // Camera::ConvertCameraPoseToRobot (:197-211): scale by the camera height, then the 3x3 extrinsics on (x, y, theta)
+    V3 camera_to_robot(const V3& c) const {
+        const double x = cfg.height * c[0], y = cfg.height * c[1], a = c[2];
+        V3 r;
+        for (int i = 0; i < 3; ++i) r[i] = cfg.extrinsics[3 * i] * x + cfg.extrinsics[3 * i + 1] * y + cfg.extrinsics[3 * i + 2] * a;
+        return r;
+    }
+    V3 image_plane_to_robot(const V3& p) const { return camera_to_robot(image_plane_to_camera(p)); }
+};
+
+namespace {
+
+// first frame: Initialize() (map_builder.cc:86-97): identity image-plane pose; it becomes the keyframe
+void first_frame(nik_tracker* t, nik_frame slot, nik_track_output& o) {
+    V3 cf{}; cf[0] = cf[1] = cf[2] = 0.0;
+    const V3 real = t->image_plane_to_camera(cf), robot = t->camera_to_robot(real);
+    memset(&o, 0, sizeof(o));
+    o.frame_id = t->frame_id++; o.inserted = 1; o.good_tracking = 0; o.key_frame_id = -1; o.slot = slot;
+    for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cf[k]; o.robot_pose[k] = robot[k]; }
+    t->distance = 0; t->init = true;
+    t->last_cf_pose = cf; t->last_cf_real_pose = real; t->last_pose = robot;         // UpdateIntermedium (:99-106)
+    t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot);
+}
+
+// everything AddNewInput does with one ComputePose result (map_builder.cc:42-68); returns whether it was inserted
+bool apply_result(nik_tracker* t, const nik_pose_result& r, nik_frame slot, nik_track_output& o) {
+    memset(&o, 0, sizeof(o));
+    o.frame_id = t->frame_id++; o.key_frame_id = t->key_frame_id; o.slot = -1;
+    for (int k = 0; k < 3; ++k) o.response[k] = r.info[k];
+    // Tracking() (:127-138)
+    V3 rel; rel[0] = r.pose[0]; rel[1] = r.pose[1]; rel[2] = r.pose[2];
+    rel = t->center_to_principal(rel);
+    const bool good = r.info[0] > t->cfg.lower_response_thr && r.info[2] > t->cfg.lower_response_thr;
+    o.good_tracking = good;
+    V3 cur_cf = t->last_cf_pose, cur_real = t->last_cf_real_pose, cur_pose = t->last_pose;
+    bool insert = false;
+    if (good) {
+        cur_cf = compute_absolute_pose(t->last_cf_pose, rel);
+        cur_real = t->image_plane_to_camera(cur_cf);
+        // UpdateCurrentPose() (:118-125)
+        const V3 last_robot_cf = t->image_plane_to_robot(t->last_cf_pose), cur_robot_cf = t->image_plane_to_robot(cur_cf);
+        cur_pose = compute_absolute_pose(t->last_pose, compute_relative_pose(last_robot_cf, cur_robot_cf));
+        // ComputeRelativeDA() (:158-166) and the keyframe rule (:47-53)
+        V3 d; for (int k = 0; k < 3; ++k) d[k] = cur_cf[k] - t->last_cf_pose[k];
+        const V3 dc = t->image_plane_to_camera(d);
+        const double dist = std::sqrt(dc[0] * dc[0] + dc[1] * dc[1]), ang = std::fabs(dc[2]);
+        const bool c1 = dist > t->cfg.max_distance, c2 = ang > t->cfg.max_angle;
+        const bool c3 = r.info[0] > t->cfg.lower_response_thr && r.info[0] < t->cfg.upper_response_thr;
+        const bool c4 = r.info[2] > t->cfg.lower_response_thr && r.info[2] < t->cfg.upper_response_thr;
+        insert = c1 || c2 || c3 || c4;
+        if (insert) t->distance += dist;
+    }
+    for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cur_cf[k]; o.robot_pose[k] = cur_pose[k]; }
+    o.inserted = insert;
+    if (insert) {
+        // UpdateIntermedium() (:99-106): this frame is the new keyframe
+        t->last_cf_pose = cur_cf; t->last_cf_real_pose = cur_real; t->last_pose = cur_pose;
+        t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot); o.slot = slot;
+    }
+    return insert;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker** out) {
+    if (!ctx || !cfg || !out) return NIK_ERR_INVALID_ARG;
+    int dims[6];
+    int rc = nik_get_dims(ctx, dims);
+    if (rc) return rc;
+    if (cfg->fx == 0 || cfg->fy == 0 || cfg->height < 0) return NIK_ERR_INVALID_ARG;   // camera.cc:199-202 refuses height < 0
+    nik_tracker* t = new nik_tracker();
+    t->ctx = ctx; t->cfg = *cfg; t->H = dims[0]; t->W = dims[1]; t->max_batch = dims[4]; t->max_frames = dims[5];
+    for (int s = t->max_frames - 1; s >= 0; --s) t->free_slots.push_back(s);          // pop_back hands out 0, 1, 2, ...
+    *out = t;
+    return NIK_OK;
+}
+
+void nik_tracker_destroy(nik_tracker* t) { delete t; }
+
+int nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n) {
+    if (!t || !n) return NIK_ERR_INVALID_ARG;
+    *n = (int)t->keyframes.size();
+    for (int i = 0; i < *n && i < cap && slots; ++i) slots[i] = t->keyframes[i];
+    return NIK_OK;
+}
+
+int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out) {
+    if (!t || !d_gray || !out || n < 0) return NIK_ERR_INVALID_ARG;
+    if (n == 0) return NIK_OK;
+    if (n > t->max_batch) return NIK_ERR_CAPACITY;
+    if ((int)t->free_slots.size() < n) return NIK_ERR_CAPACITY;
+    std::vector<nik_frame> slot(n);
+    for (int i = 0; i < n; ++i) { slot[i] = t->free_slots.back(); t->free_slots.pop_back(); }
+    std::vector<nik_pose_result> res(n);
+    std::vector<nik_frame> keys(n);
+    int rc, start = 0;
+    bool have_spectra = false;               // spectra of frames [start, n) already on the device
+    const size_t fsz = (size_t)t->H * t->W;
+
+    if (!t->init) {
+        if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return rc;
+        have_spectra = true;
+        first_frame(t, slot[0], out[0]);
+        start = 1;
+    }
+    while (start < n) {
+        const int m = n - start;
+        for (int i = 0; i < m; ++i) keys[i] = t->key_slot;
+        // register every remaining frame against the current keyframe in one batch (speculative: valid up to and
+        // including the next inserted frame)
+        if (!have_spectra) rc = nik_track_batch_dev(t->ctx, m, d_gray + (size_t)start * fsz, keys.data(), slot.data() + start, 1, res.data(), 1);
+        else rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data());
+        if (rc) return rc;
+        have_spectra = true;
+        int i = start;
+        while (i < n) {
+            const bool inserted = apply_result(t, res[i - start], slot[i], out[i]);
+            ++i;
+            if (inserted) break;             // the frames after it must be registered against the new keyframe
+        }
+        start = i;
+    }
+    // recycle the slots of frames that did not become keyframes
+    for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]);
+    return NIK_OK;
+}
+
+int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out) {
+    if (!t || !gray || !out) return NIK_ERR_INVALID_ARG;
+    if (t->free_slots.empty()) return NIK_ERR_CAPACITY;
+    // host frame: upload through the single-frame entry point, then run the same logic with the spectra in place
+    const nik_frame s = t->free_slots.back();
+    int rc = nik_intermedium_u8(t->ctx, gray, stride, s);
+    if (rc) return rc;
+    t->free_slots.pop_back();
+    if (!t->init) { first_frame(t, s, *out); return NIK_OK; }
+    nik_pose_result r;
+    if ((rc = nik_pose(t->ctx, t->key_slot, s, 1, nullptr, nullptr, &r))) { t->free_slots.push_back(s); return rc; }
+    if (!apply_result(t, r, s, *out)) t->free_slots.push_back(s);
+    return NIK_OK;
+}
+
+}  // extern "C"

@@ -24,7 +24,8 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
-           "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams"]
+           "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
+           "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
 
 
 class NikConfig(C.Structure):
@@ -46,6 +47,23 @@ class NikPoseResult(C.Structure):
                     trans_row=list(self.trans_row), trans_col=list(self.trans_col), psr_rot=float(self.psr_rot),
                     psr_trans=[float(v) for v in self.psr_trans], degree_final=float(self.degree_final),
                     chosen=self.chosen, n_hyp=self.n_hyp)
+
+
+class NikTrackerConfig(C.Structure):
+    """camera intrinsics after undistortion + KeyframeSelectionConfig (reference camera.cc:20-75, read_configs.h:27-32)"""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("height", C.c_double),
+                ("extrinsics", C.c_double * 9), ("max_distance", C.c_double), ("max_angle", C.c_double),
+                ("lower_response_thr", C.c_double), ("upper_response_thr", C.c_double)]
+
+
+class NikTrackOutput(C.Structure):
+    _fields_ = [("frame_id", C.c_int32), ("inserted", C.c_int32), ("good_tracking", C.c_int32), ("key_frame_id", C.c_int32),
+                ("slot", C.c_int32), ("response", C.c_double * 3), ("cf_pose", C.c_double * 3), ("robot_pose", C.c_double * 3)]
+
+    def as_dict(self):
+        return dict(frame_id=self.frame_id, inserted=bool(self.inserted), good_tracking=bool(self.good_tracking),
+                    key_frame_id=self.key_frame_id, slot=self.slot, response=list(self.response), cf_pose=list(self.cf_pose),
+                    robot_pose=list(self.robot_pose))
 
 
 class NikStageStat(C.Structure):
@@ -107,6 +125,12 @@ def load():
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
         L.nik_dbg_polar.argtypes = [P, P, P]
         L.nik_profile_enable.argtypes = [P, I]
+        L.nik_tracker_create.argtypes = [P, C.POINTER(NikTrackerConfig), C.POINTER(P)]
+        L.nik_tracker_destroy.argtypes = [P]
+        L.nik_tracker_destroy.restype = None
+        L.nik_tracker_push_dev.argtypes = [P, I, P, P]
+        L.nik_tracker_push_u8.argtypes = [P, P, I, P]
+        L.nik_tracker_keyframes.argtypes = [P, P, I, P]
         L.nik_dbg_set_ablate.argtypes = [I]
         L.nik_profile_read.argtypes = [P, P, I, P]
         _lib = L
@@ -269,3 +293,52 @@ class CorrelationFlow:
         out = np.empty((self.PC, self.PD), np.float32)
         self._chk(self._L.nik_dbg_polar(self._ctx, _p(x), _p(out)))
         return out
+
+
+def tracker_config(fx=600.0, fy=600.0, cx=320.0, cy=240.0, height=0.1, max_distance=0.4, max_angle=0.052359877,
+                   lower_response_thr=30.0, upper_response_thr=90.0):
+    """defaults: SURVEY.md 8(d) synthetic camera + reference configs/config_ntu.yaml:19-23"""
+    cfg = NikTrackerConfig(fx=fx, fy=fy, cx=cx, cy=cy, height=height, max_distance=max_distance, max_angle=max_angle,
+                           lower_response_thr=lower_response_thr, upper_response_thr=upper_response_thr)
+    for i, v in enumerate([1, 0, 0, 0, 1, 0, 0, 0, 1]):
+        cfg.extrinsics[i] = float(v)
+    return cfg
+
+
+class Tracker:
+    """the tracking subset of the reference MapBuilder (map_builder.cc:30-138) on top of a CorrelationFlow context"""
+
+    def __init__(self, flow, cfg):
+        self._flow, self._L = flow, flow._L
+        self._t = C.c_void_p()
+        rc = self._L.nik_tracker_create(flow._ctx, C.byref(cfg), C.byref(self._t))
+        if rc:
+            raise NikError(rc, "nik_tracker_create failed")
+
+    def close(self):
+        if getattr(self, "_t", None):
+            self._L.nik_tracker_destroy(self._t)
+            self._t = None
+
+    __del__ = close
+
+    def push_dev(self, d_gray_ptr, n):
+        out = (NikTrackOutput * n)()
+        rc = self._L.nik_tracker_push_dev(self._t, int(n), C.c_void_p(int(d_gray_ptr)), C.cast(out, C.c_void_p))
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
+        return [o.as_dict() for o in out]
+
+    def push_u8(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        out = NikTrackOutput()
+        rc = self._L.nik_tracker_push_u8(self._t, _p(gray), gray.shape[1], C.addressof(out))
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
+        return out.as_dict()
+
+    def keyframes(self):
+        slots = np.zeros(self._flow.max_frames, np.int32)
+        n = C.c_int(0)
+        self._L.nik_tracker_keyframes(self._t, _p(slots), len(slots), C.addressof(n))
+        return slots[: n.value].tolist()

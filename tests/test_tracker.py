@@ -1,0 +1,79 @@
+"""Sequence driver: the C++ tracker over the HIP path against the CPU restatement of the
+MapBuilder tracking subset over the oracle, on a seeded synthetic trajectory with keyframe switches."""
+import math
+
+import numpy as np
+import pytest
+
+import synth
+from kcc_helpers import SMALL, FULL, nik
+from oracle import kcc_oracle as ko
+from ref_tracker import RefTracker, compute_absolute_pose, compute_relative_pose, normalize_angle
+
+
+def _trajectory(geom, n, seed):
+    """window drifting over one canvas: steady motion + slow rotation, so keyframes get inserted by the rule"""
+    H, W = geom["H"], geom["W"]
+    cv = synth.canvas(seed, H, W)
+    rng = np.random.default_rng(seed)
+    frames, dy, dx, th = [], 0.0, 0.0, 0.0
+    step = max(1.0, min(H, W) / 60.0)
+    for i in range(n):
+        frames.append(synth.window(cv, H, W, int(round(dy)), int(round(dx)), round(th * 2) / 2))
+        dy += step * rng.uniform(0.2, 1.0)
+        dx += step * rng.uniform(-1.0, 0.6)
+        th += rng.uniform(-0.4, 0.6)
+    return np.stack(frames)
+
+
+def test_se2_helpers():
+    p1, p2 = np.array([1.0, 2.0, 0.3]), np.array([-0.5, 4.0, -2.9])
+    rel = compute_relative_pose(p1, p2)
+    back = compute_absolute_pose(p1, rel)
+    assert np.allclose(back[:2], p2[:2]) and abs(normalize_angle(back[2] - p2[2])) < 1e-12
+    assert normalize_angle(math.pi) == pytest.approx(-math.pi)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom,n,window", [pytest.param(SMALL, 24, 8, id="60x80"), pytest.param(FULL, 10, 5, id="480x640")])
+def test_tracker_matches_reference_logic(geom, n, window):
+    import torch
+    N = nik()
+    H, W = geom["H"], geom["W"]
+    frames = _trajectory(geom, n, 77)
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    flow = N.CorrelationFlow(cfg, H, W, max_batch=window, max_frames=n + window + 2)
+    # thresholds scaled to the geometry: small images have PSR ~ 20-30
+    lower, upper = (12.0, 26.0) if geom is SMALL else (30.0, 140.0)
+    tc = N.tracker_config(fx=600.0 * W / 640, fy=600.0 * W / 640, cx=W / 2 - 3.5, cy=H / 2 + 2.25, height=0.1,
+                          max_distance=0.02, max_angle=0.02, lower_response_thr=lower, upper_response_thr=upper)
+    trk = N.Tracker(flow, tc)
+    d = torch.from_numpy(frames).cuda()
+    torch.cuda.synchronize()
+    got = []
+    for b in range(0, n, window):
+        m = min(window, n - b)
+        got += trk.push_dev(d[b:b + m].data_ptr(), m)
+    ocfg = ko.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    ref = RefTracker(ko.Oracle(ocfg, H, W), H, W, fx=tc.fx, fy=tc.fy, cx=tc.cx, cy=tc.cy, height=tc.height,
+                     max_distance=tc.max_distance, max_angle=tc.max_angle, lower=lower, upper=upper)
+    want = [ref.add_new_input(f) for f in frames]
+    n_key = 0
+    for g, w in zip(got, want):
+        assert (g["frame_id"], g["inserted"], g["good_tracking"], g["key_frame_id"]) == \
+               (w["frame_id"], w["inserted"], w["good_tracking"], w["key_frame_id"]), (g, w)
+        assert g["response"] == pytest.approx(w["response"], rel=3e-3, abs=1e-9)
+        assert g["cf_pose"][:2] == pytest.approx(w["cf_pose"][:2], abs=1e-9)
+        assert abs(normalize_angle(g["cf_pose"][2] - w["cf_pose"][2])) < 1e-9
+        assert g["robot_pose"][:2] == pytest.approx(w["robot_pose"][:2], abs=1e-12)
+        n_key += g["inserted"]
+    assert 2 <= n_key < n, "the trajectory should exercise both keyframe insertion and plain tracking (%d)" % n_key
+    assert len(trk.keyframes()) == n_key
+    # the single-frame host entry point gives the same answers as the batched speculative one
+    flow2 = N.CorrelationFlow(cfg, H, W, max_batch=2, max_frames=n + 2)
+    trk2 = N.Tracker(flow2, tc)
+    for f, g in zip(frames[: min(n, 8)], got):
+        o = trk2.push_u8(f)
+        for k in ("frame_id", "inserted", "good_tracking", "key_frame_id", "response", "cf_pose", "robot_pose"):
+            assert o[k] == g[k], k
+    trk.close(); trk2.close(); flow.close(); flow2.close()
