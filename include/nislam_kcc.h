@@ -130,9 +130,21 @@ int nik_track_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_fr
 /* replaces the per-candidate loop of LoopClosure::FindLoopClosure (loop_closure.cc:40-66): runs
  * ComputePose(cand_i, query, not_large_rotation=false) for n candidates and returns every result
  * plus the index of the candidate with the largest response.sum() (first such in `cands` order),
- * or -1 when n == 0.  The frame-gap / distance filters (:43-53) stay with the caller. */
+ * or -1 when n == 0.  The frame-gap / distance filters (:43-53) stay with the caller.  n may exceed max_batch
+ * (candidates are processed max_batch at a time). */
 int nik_match(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands,
               int* best, nik_pose_result* res /* n entries, may be NULL */, nik_pose_result* best_res);
+
+/* Extension (no reference counterpart): two-stage search.  Stage 1 ranks all n candidates by
+ * the rotation-stage PSR (info[2]; needs only the cached polar spectra), stage 2 runs the reference's full
+ * ComputePose on the k best and applies nik_match's selection rule to them.  shortlist (optional, k ints)
+ * receives the candidate indices that reached stage 2. */
+int nik_match_topk(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands, int k, int* best,
+                   nik_pose_result* best_res, int* shortlist);
+
+/* Extension (config 4): interleaved 8-bit RGB (bgr=0) or BGR (bgr=1) images in HBM -> 8-bit gray with OpenCV's
+ * integer luma weights (R*4899 + G*9617 + B*1868 + 8192) >> 14; n images of H x W.  The reference loads gray. */
+int nik_rgb_to_gray_dev(nik_ctx* ctx, int n, const uint8_t* d_rgb, int bgr, uint8_t* d_gray);
 
 /* ---- sequence driver: the tracking subset of MapBuilder ---------------- */
 

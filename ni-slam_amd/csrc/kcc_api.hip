@@ -10,6 +10,7 @@
 #include "../../include/nislam_kcc.h"
 #include "kcc_kernels.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -777,23 +778,110 @@ int nik_track_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const nik_fram
     return sync ? drain_all(c) : NIK_OK;
 }
 
+int nik_rgb_to_gray_dev(nik_ctx* c, int n, const uint8_t* d_rgb, int bgr, uint8_t* d_gray) {
+    if (!c || !d_rgb || !d_gray || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (n == 0) return NIK_OK;
+    // runs on lane 0 and is ordered before later calls by a full drain (colour conversion is not on the timed path)
+    int rc = drain_all(c);
+    if (rc) return rc;
+    launch_rgb2gray(c->lanes[0].stream, d_rgb, d_gray, (size_t)n * c->img.real_elems, bgr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->lanes[0].stream));
+    return NIK_OK;
+}
+
 int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* best, nik_pose_result* res,
               nik_pose_result* best_res) {
     if (!c || (n > 0 && !cands) || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
     if (best) *best = -1;
     if (n == 0) return NIK_OK;
-    std::vector<nik_frame> curs(n, query);
     std::vector<nik_pose_result> local;
     if (!res) { local.resize(n); res = local.data(); }
-    int rc = nik_pose_batch(c, n, cands, curs.data(), 0, res);       // loop_closure.cc:58-59 (not_large_rotation=false)
-    if (rc) return rc;
-    int b = -1; double bs = -3.0;                                    // LoopClosureResult(): response(-1,-1,-1)  (loop_closure.h:14)
+    int rc;
+    if ((rc = check_kernel(c))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, cands[i], true))) return rc;
+    if ((rc = check_slot(c, query, true))) return rc;
+    // ComputePose(cand_i, query, not_large_rotation=false) for every candidate (loop_closure.cc:58-59), max_batch at a time;
+    // the chunks are queued back to back (two in flight per lane) and finalised by the drain
+    std::vector<nik_frame> curs(std::min(n, c->max_batch), query);
+    for (int b = 0; b < n; b += c->max_batch) {
+        const int m = std::min(c->max_batch, n - b);
+        if ((rc = pose_call(c, m, nullptr, cands + b, curs.data(), 0, res + b))) return rc;
+    }
+    if ((rc = drain_all(c))) return rc;
+    int bi = -1; double bs = -3.0;                                   // LoopClosureResult(): response(-1,-1,-1)  (loop_closure.h:14)
     for (int i = 0; i < n; ++i) {
         const double s = res[i].info[0] + res[i].info[1] + res[i].info[2];
-        if (s > bs) { bs = s; b = i; }                               // loop_closure.cc:61 strict >
+        if (s > bs) { bs = s; bi = i; }                              // loop_closure.cc:61 strict >
     }
-    if (best) *best = b;
-    if (best_res && b >= 0) *best_res = res[b];
+    if (best) *best = bi;
+    if (best_res && bi >= 0) *best_res = res[bi];
+    return NIK_OK;
+}
+
+// rotation stage only (EstimateTrans on the cached polar spectra): PSR_r and arg-max row per candidate
+static int rotation_call(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, float* psr_rot, int* rot_row) {
+    int rc;
+    struct Part { Lane* L; Call* call; int b, m; };
+    std::vector<Part> parts;
+    const int nl = lanes_for(c, n);
+    for (int li = 0; li < nl; ++li) {
+        int b, e; chunk_of(n, nl, li, b, e);
+        const int m = e - b; if (m <= 0) continue;
+        Lane& L = c->lanes[li];
+        if ((rc = begin_call(c, L))) return rc;
+        for (int i = b; i < e; ++i) {
+            if ((rc = depend_on_slot(c, L, li, keys[i])) || (rc = depend_on_slot(c, L, li, curs[i]))) return rc;
+            note_read(c, L, li, keys[i]); note_read(c, L, li, curs[i]);
+        }
+        if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, 1, false))) return rc;
+        enqueue_estimate(c, L, m, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
+                         c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, nullptr, 1);
+        HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * m, hipMemcpyDeviceToHost, L.stream));
+        HIP_TRY(c, hipGetLastError());
+        L.cur->has_pose = false;
+        if ((rc = end_call(c, L))) return rc;
+        parts.push_back({ &L, L.cur, b, m });
+    }
+    for (const Part& p : parts) {
+        HIP_TRY(c, hipEventSynchronize(p.call->done));
+        for (int i = 0; i < p.m; ++i) {
+            psr_rot[p.b + i] = psr_from(p.call->h_rot[i], (long)c->PD * c->PC);
+            rot_row[p.b + i] = p.call->h_rot[i].idx % c->PD;
+        }
+    }
+    return NIK_OK;
+}
+
+int nik_match_topk(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int k, int* best,
+                   nik_pose_result* best_res, int* shortlist) {
+    if (!c || (n > 0 && !cands) || n < 0 || k <= 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (best) *best = -1;
+    if (n == 0) return NIK_OK;
+    int rc;
+    if ((rc = check_kernel(c)) || (rc = check_slot(c, query, true))) return rc;
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, cands[i], true))) return rc;
+    if ((rc = drain_all(c))) return rc;
+    // stage 1: rank every candidate by the rotation-stage PSR (needs only the cached polar spectra)
+    std::vector<float> psr(n); std::vector<int> row(n);
+    std::vector<nik_frame> curs(std::min(n, c->max_batch), query);
+    for (int b = 0; b < n; b += c->max_batch) {
+        const int m = std::min(c->max_batch, n - b);
+        if ((rc = rotation_call(c, m, cands + b, curs.data(), psr.data() + b, row.data() + b))) return rc;
+    }
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    k = std::min(k, n);
+    std::partial_sort(order.begin(), order.begin() + k, order.end(),
+                      [&](int a, int b2) { return psr[a] > psr[b2] || (psr[a] == psr[b2] && a < b2); });
+    std::sort(order.begin(), order.begin() + k);              // keep candidate order: ties resolve as in the exact search
+    // stage 2: the reference's full two-hypothesis ComputePose on the short list only
+    std::vector<nik_frame> top(k);
+    for (int i = 0; i < k; ++i) { top[i] = cands[order[i]]; if (shortlist) shortlist[i] = order[i]; }
+    std::vector<nik_pose_result> res(k);
+    int bi = -1;
+    if ((rc = nik_match(c, query, k, top.data(), &bi, res.data(), best_res))) return rc;
+    if (best) *best = bi >= 0 ? order[bi] : -1;
     return NIK_OK;
 }
 

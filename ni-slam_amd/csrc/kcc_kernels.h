@@ -60,6 +60,9 @@ PlanDesc plan_desc(int n);
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,
                    int H, int W);
 
+// 8-bit RGB/BGR (interleaved) -> gray with OpenCV's integer luma weights
+void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr);
+
 // ---- A-type: lines along `rows` (r2c / c2r), transposed spectrum access ----
 // forward from a real plane: src plane index = src_idx ? src_idx[item] : item
 void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride,

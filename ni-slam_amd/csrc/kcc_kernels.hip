@@ -146,6 +146,18 @@ __global__ void k_cvt_u8(const uint8_t* __restrict__ src, const int* __restrict_
     }
 }
 
+// cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit data: (R*4899 + G*9617 + B*1868 + 8192) >> 14  [recalled]
+__global__ void k_rgb2gray(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t npix, int bgr) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t* p = rgb + 3 * i;
+    const int r = bgr ? p[2] : p[0], g = p[1], b = bgr ? p[0] : p[2];
+    gray[i] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+}
+void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr) {
+    hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
+}
+
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img, int H, int W) {
     dim3 grid((W + 31) / 32, (H + 31) / 32, n), block(32, 8);
     hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, d_gray, d_dst_slot, arena_img, H, W);

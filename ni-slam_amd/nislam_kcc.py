@@ -25,7 +25,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
-           "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
+           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
 
 
 class NikConfig(C.Structure):
@@ -120,6 +120,8 @@ def load():
         L.nik_pose_batch.argtypes = [P, I, P, P, I, P]
         L.nik_track_batch_dev.argtypes = [P, I, P, P, P, I, P, I]
         L.nik_match.argtypes = [P, I, I, P, P, P, P]
+        L.nik_match_topk.argtypes = [P, I, I, P, I, P, P, P]
+        L.nik_rgb_to_gray_dev.argtypes = [P, I, P, I, P]
         L.nik_dbg_fft.argtypes = [P, I, P, P]
         L.nik_dbg_ifft.argtypes = [P, I, P, P]
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
@@ -256,6 +258,19 @@ class CorrelationFlow:
         self._chk(self._L.nik_match(self._ctx, int(query), n, _p(cands), C.addressof(best), C.cast(res, C.c_void_p),
                                     C.addressof(best_res)))
         return best.value, [res[i].as_dict() for i in range(n)], best_res.as_dict()
+
+    def match_topk(self, query, cands, k):
+        cands = _i32(cands)
+        n = len(cands)
+        best, best_res = C.c_int(-1), NikPoseResult()
+        short = np.full(max(1, min(k, n)), -1, np.int32)
+        self._chk(self._L.nik_match_topk(self._ctx, int(query), n, _p(cands), int(k), C.addressof(best),
+                                         C.addressof(best_res), _p(short)))
+        return best.value, best_res.as_dict(), short.tolist()
+
+    def rgb_to_gray_dev(self, d_rgb_ptr, n, d_gray_ptr, bgr=False):
+        self._chk(self._L.nik_rgb_to_gray_dev(self._ctx, int(n), C.c_void_p(int(d_rgb_ptr)), int(bool(bgr)),
+                                              C.c_void_p(int(d_gray_ptr))))
 
     # ---- measurement -------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -247,3 +247,80 @@ def test_error_behaviour():
     with pytest.raises(N.NikError) as e:
         N.CorrelationFlow(good, 61, 80)                    # odd height: the reference silently mis-sizes (:67); we refuse
     assert e.value.code == N.NIK_ERR_UNSUPPORTED_SIZE
+
+
+def test_match_chunked_and_topk():
+    """config 5: more candidates than max_batch; exact search vs the two-stage top-k extension."""
+    geom, n, mb = SMALL, 40, 16
+    cf, orc, ocfg = _mk(geom, max_batch=mb, max_frames=n + 1)
+    H, W = geom["H"], geom["W"]
+    rng = np.random.default_rng(9)
+    truth = 27
+    cv = synth.canvas(600, H, W)
+    query = synth.window(cv, H, W, 3, 2, 0.0)
+    cands = [synth.window(synth.canvas(700 + i, H, W), H, W, int(rng.integers(-3, 4)), int(rng.integers(-3, 4))) for i in range(n)]
+    cands[truth] = synth.window(cv, H, W)
+    import torch
+    d = torch.from_numpy(np.stack(cands)).cuda()
+    torch.cuda.synchronize()
+    for b in range(0, n, mb):
+        m = min(mb, n - b)
+        cf.intermedium_batch_dev(d[b:b + m].data_ptr(), m, list(range(b, b + m)))
+    cf.intermedium_u8(query, n)
+    best, res, best_res = cf.match(n, list(range(n)))
+    assert best == truth and (best_res["pose"][0], best_res["pose"][1]) == (2, 3)
+    # every candidate's result equals the one-at-a-time answer (chunking / lanes do not change outputs)
+    for i in (0, mb - 1, mb, n - 1, truth):
+        _, _, one = cf.pose(i, n, False)
+        assert one == res[i]
+    # oracle agrees on the winner and on its registration
+    qf = orc.normalize_u8(query)
+    _, qp = orc.intermedium(qf)
+    kf, kp = orc.intermedium(orc.normalize_u8(cands[truth]))
+    pose, info, dbg = orc.compute_pose(kf, qf, kp, qp, False)
+    ok, _, msg = check_pose_parity(best_res, pose, info, dbg, geom["PD"], psr_rtol=5e-3)
+    assert ok, msg
+    # two-stage extension: the rotation-PSR short list must contain the true loop and return the same answer
+    b2, r2, short = cf.match_topk(n, list(range(n)), 8)
+    assert truth in short and b2 == truth and r2 == best_res
+    assert cf.match_topk(n, list(range(n)), 1000)[0] == truth          # k >= n degenerates to the exact search
+    cf.close()
+
+
+def test_rgb_1280x720_parity():
+    """config 4: 1280x720 RGB -> integer luma -> the standard pair; parity with the oracle."""
+    import torch
+    N = nik()
+    H, W = 720, 1280
+    n = 2
+    keys, curs, motions = synth.make_batch(n, H, W, seed0=800, max_shift=40, max_theta=6.0)
+    rng = np.random.default_rng(1)
+
+    def colourise(g):          # an RGB image whose luma is NOT trivially the input: independent channel perturbations
+        rgb = np.stack([g, g, g], -1).astype(np.int16) + rng.integers(-20, 21, g.shape + (3,))
+        return np.clip(rgb, 0, 255).astype(np.uint8)
+    k_rgb, c_rgb = np.stack([colourise(g) for g in keys]), np.stack([colourise(g) for g in curs])
+
+    def luma(rgb):
+        r, g, b = (rgb[..., i].astype(np.int64) for i in range(3))
+        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+    cfg = N.default_config()
+    cf = N.CorrelationFlow(cfg, H, W, max_batch=n, max_frames=2 * n)
+    d_rgb = torch.from_numpy(np.concatenate([k_rgb, c_rgb])).cuda()
+    d_gray = torch.empty((2 * n, H, W), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    cf.rgb_to_gray_dev(d_rgb.data_ptr(), 2 * n, d_gray.data_ptr())
+    gray = d_gray.cpu().numpy()
+    assert np.array_equal(gray[:n], luma(k_rgb)) and np.array_equal(gray[n:], luma(c_rgb))
+    # BGR order flips the weights
+    cf.rgb_to_gray_dev(d_rgb.data_ptr(), 1, d_gray[:1].data_ptr(), bgr=True)
+    assert np.array_equal(d_gray[0].cpu().numpy(), luma(k_rgb[0][..., ::-1]))
+    cf.rgb_to_gray_dev(d_rgb.data_ptr(), 2 * n, d_gray.data_ptr())
+    cf.intermedium_batch_dev(d_gray[:n].data_ptr(), n, list(range(n)))
+    res = cf.track_batch_dev(d_gray[n:].data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)
+    ocfg = ko.default_config()
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, gray[:n], gray[n:], True, nthreads=n)
+    for i in range(n):
+        ok, _, msg = check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], 720)
+        assert ok, "pair %d %s: %s" % (i, motions[i], msg)
+    cf.close()
