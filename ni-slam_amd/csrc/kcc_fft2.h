@@ -116,6 +116,16 @@ template <> struct PlanFor<480> : Plan<480, KCC_P480> {};
 template <> struct PlanFor<640> : Plan<640, KCC_P640> {};
 template <> struct PlanFor<1280> : Plan<1280, 8, 10, 16> {};
 
+// Plan used by the spectrum-in (inverse) A-type kernels; may differ from PlanFor (their tile width, hence their
+// thread budget, differs).  Default: the same plan.
+template <int N> struct PlanInv : PlanFor<N> {};
+#ifdef KCC_PI240
+template <> struct PlanInv<240> : Plan<240, KCC_PI240> {};
+#endif
+#ifdef KCC_PI360
+template <> struct PlanInv<360> : Plan<360, KCC_PI360> {};
+#endif
+
 // Twiddle table layout (built on the host, see kcc_api.hip build_plan_tables):
 //   2 passes, direction d:  tw[q*RF + k] = W_N^(+-q*k),            q < RL, k < RF
 //   3 passes, direction d:  tw[q*RF + k] = W_(RF*RM)^(+-q*k),      q < RM, k < RF          (pass 2)

@@ -47,6 +47,8 @@ bool fft_line_supported(int n);   // cols instantiated?
 struct Tables {
     const float2* half_f;    // plan of length rows/2, forward
     const float2* half_i;    // plan of length rows/2, inverse
+    const float2* halfI_f;   // plan of the spectrum-in A kernels (PlanInv), forward / inverse
+    const float2* halfI_i;
     const float2* tw_full;   // W_{2h}^k, k < h: r2c / c2r split twiddles
     const float2* cols_f;    // plan of length cols, forward
     const float2* cols_i;    // plan of length cols, inverse
@@ -55,6 +57,7 @@ struct Tables {
 // radices of the instantiated plan for length n (np = 0 if n is not instantiated)
 struct PlanDesc { int n, np, r[3]; };
 PlanDesc plan_desc(int n);
+PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for half length n
 
 // ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,

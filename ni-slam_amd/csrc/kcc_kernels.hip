@@ -11,6 +11,8 @@
 #include "kcc_kernels.h"
 #include "kcc_fft2.h"
 
+#include <type_traits>
+
 namespace kcc {
 
 // ------------------------------------------------------------------------------------------------
@@ -30,6 +32,13 @@ bool fft_line_supported(int n_) {
     KCC_LINE_LIST(X)
 #undef X
     return false;
+}
+PlanDesc plan_desc_inv(int n_) {
+    PlanDesc d{ n_, 0, { 1, 1, 1 } };
+#define X(n) if (n_ == n) { using P = PlanInv<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; }
+    KCC_HALF_LIST(X)
+#undef X
+    return d;
 }
 PlanDesc plan_desc(int n_) {
     PlanDesc d{ n_, 0, { 1, 1, 1 } };
@@ -128,21 +137,32 @@ __device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& i
 // ------------------------------------------------------------------------------------------------
 // u8 row-major -> f32 column-major, /255  (utils.cc:110-118)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_cvt_u8(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot, float* __restrict__ arena,
-                         int H, int W) {
-    __shared__ float tile[32][33];
-    const int item = blockIdx.z;
+// 64 x 64 tile per workgroup: rows are read as uchar4 (64-byte row segments), transposed through LDS and written
+// as float4 along y (256-byte column segments).  Requires W % 4 == 0 and H % 4 == 0 (always true here).
+__global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
+                                                float* __restrict__ arena, int H, int W) {
+    __shared__ float tile[64][65];                          // [x][y], odd pitch
+    const int item = blockIdx.z, tid = threadIdx.x;
     const uint8_t* in = src + (size_t)item * H * W;
     float* out = arena + (size_t)dst_slot[item] * H * W;
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
-        const int r = r0 + j, c = c0 + threadIdx.x;
-        if (r < H && c < W) tile[j][threadIdx.x] = (float)in[(size_t)r * W + c] / 255.0f;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = r0 + (tid >> 4) + 16 * it, c = c0 + 4 * (tid & 15);
+        if (r < H && c < W) {
+            const uchar4 v = *reinterpret_cast<const uchar4*>(in + (size_t)r * W + c);
+            const int y = (tid >> 4) + 16 * it, x = 4 * (tid & 15);
+            tile[x + 0][y] = (float)v.x / 255.0f; tile[x + 1][y] = (float)v.y / 255.0f;
+            tile[x + 2][y] = (float)v.z / 255.0f; tile[x + 3][y] = (float)v.w / 255.0f;
+        }
     }
     __syncthreads();
-    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
-        const int c = c0 + j, r = r0 + threadIdx.x;
-        if (r < H && c < W) out[(size_t)c * H + r] = tile[threadIdx.x][j];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int x = (tid >> 4) + 16 * it, y = 4 * (tid & 15);
+        const int c = c0 + x, r = r0 + y;
+        if (c < W && r < H)
+            *reinterpret_cast<float4*>(out + (size_t)c * H + r) = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
     }
 }
 
@@ -159,7 +179,7 @@ void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t np
 }
 
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img, int H, int W) {
-    dim3 grid((W + 31) / 32, (H + 31) / 32, n), block(32, 8);
+    dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
     hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, d_gray, d_dst_slot, arena_img, H, W);
 }
 
@@ -173,6 +193,7 @@ __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POL
 struct AArgs {
     int rows, cols, hr, n_items, ablate;
     const float2* tw_f; const float2* tw_i; const float2* tw_full;
+    const float2* twI_f; const float2* twI_i;                // tables of PlanInv (spectrum-in kernels)
     // forward source
     const float* src; size_t src_stride; const int* src_idx;
     const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
@@ -185,9 +206,9 @@ struct AArgs {
     KernelFn fn; unsigned* maxbuf; const float* energy;
 };
 
-template <int HH, int LXV> struct ACfg {
+template <int HH, int LXV, bool INVPLAN> struct ACfg {
     static constexpr int HALF = HH;
-    using P = PlanFor<HH>;
+    using P = typename std::conditional<INVPLAN, PlanInv<HH>, PlanFor<HH>>::type;
     static constexpr int T = P::T;                       // threads per line
     static constexpr int LX = LXV;
     static constexpr int NT = LX * T;
@@ -234,8 +255,8 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int S
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
-template <int HH> using FCfg = ACfg<HH, KCC_ALX>;            // forward (real -> spectrum) kernels
-template <int HH> using ICfg = ACfg<HH, a_lx(HH)>;           // inverse (spectrum -> ...) kernels
+template <int HH> using FCfg = ACfg<HH, KCC_ALX, false>;            // forward (real -> spectrum) kernels
+template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (spectrum -> ...) kernels
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
@@ -533,14 +554,14 @@ template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items,
     hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, FCfg<HH>::BYTES, s, a);
 }
 template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
-    a.n_items = n_items;
+    a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
     dim3 grid((a.cols / ICfg<HH>::LX) * n_items * nz), block(ICfg<HH>::NT);
     hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ICfg<HH>::BYTES, s, a);
 }
 
 static AArgs base_args(PlaneGeom g, Tables t) {
     AArgs a{};
-    a.ablate = g_ablate; a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full;
+    a.ablate = g_ablate; a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full; a.twI_f = t.halfI_f; a.twI_i = t.halfI_i;
     return a;
 }
 
@@ -863,19 +884,27 @@ void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, 
 // reduce the per-workgroup partials of one response surface (fixed order -> deterministic); for the rotation
 // surface also emit the de-rotation table index of every translation item of the pair:
 //   rot_index[item*n_hyp + h] = variant(h) * PD + arg-max row       (variant 0: small-rotation fold, 1/2: orig / +180)
-__global__ void k_finalize(const Partial* __restrict__ partials, int partial_stride, int n_partials, SurfaceResult* out,
-                           int* rot_index, int n_hyp, int PD) {
-    const int item = blockIdx.x;
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(64) void k_finalize(const Partial* __restrict__ partials, int partial_stride, int n_partials,
+                                                 SurfaceResult* out, int* rot_index, int n_hyp, int PD) {
+    const int item = blockIdx.x, lane = threadIdx.x;
     const Partial* p = partials + (size_t)item * partial_stride;
-    SurfaceResult r; r.sum = 0; r.sumsq = 0; r.peak = -INFINITY; r.idx = 0x7FFFFFFF;
-    for (int i = 0; i < n_partials; ++i) {
-        r.sum += p[i].sum; r.sumsq += p[i].sumsq;
-        if (p[i].peak > r.peak || (p[i].peak == r.peak && p[i].idx < r.idx)) { r.peak = p[i].peak; r.idx = p[i].idx; }
+    // one wave: lane i folds partials i, i+64, ... in index order, then a fixed butterfly -> deterministic
+    double s1 = 0, s2 = 0; float peak = -INFINITY; int idx = 0x7FFFFFFF;
+    for (int i = lane; i < n_partials; i += 64) {
+        s1 += p[i].sum; s2 += p[i].sumsq;
+        if (p[i].peak > peak || (p[i].peak == peak && p[i].idx < idx)) { peak = p[i].peak; idx = p[i].idx; }
     }
-    out[item] = r;
-    if (rot_index)
-        for (int h = 0; h < n_hyp; ++h) rot_index[item * n_hyp + h] = (n_hyp == 1 ? 0 : 1 + h) * PD + (r.idx % PD);
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float op = __shfl_xor(peak, off); const int oi = __shfl_xor(idx, off);
+        if (op > peak || (op == peak && oi < idx)) { peak = op; idx = oi; }
+        s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off);
+    }
+    if (lane == 0) {
+        SurfaceResult r; r.sum = s1; r.sumsq = s2; r.peak = peak; r.idx = idx;
+        out[item] = r;
+        if (rot_index)
+            for (int h = 0; h < n_hyp; ++h) rot_index[item * n_hyp + h] = (n_hyp == 1 ? 0 : 1 + h) * PD + (idx % PD);
+    }
 }
 void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials, SurfaceResult* out,
                      int* rot_index, int n_hyp, int PD) {
