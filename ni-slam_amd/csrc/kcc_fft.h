@@ -1,7 +1,5 @@
-// kcc_fft.h -- device-side mixed-radix (2,3,4,5,7,8) Stockham FFT on lines staged in LDS.
-// gfx950 only.  Lines live in LDS as float2[L][PITCH]; a workgroup of NT threads walks the flat
-// (line, butterfly) space so any (N, L, NT) combination is balanced.  Each pass keeps its
-// butterflies in registers: load R points -> twiddle -> radix-R DFT -> store (autosort order).
+// kcc_fft.h -- complex helpers and the base-radix butterflies {2,3,4,5,7,8} (in registers) that the
+// register-resident FFT engine of kcc_fft2.h composes into large radices.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -116,64 +114,5 @@ template <bool INV> struct Radix<8, INV> {
         v[3] = cadd(e[3], o3);   v[7] = csub(e[3], o3);
     }
 };
-
-// One Stockham pass of radix R over L lines of N points (in place in LDS, register staged).
-// tw: W_N table in LDS (tw[t] = exp(-2*pi*i*t/N)).
-template <int N, int R, int NS, int L, int NT, int PITCH, bool INV>
-__device__ __forceinline__ void fft_pass(float2* lds, const float2* tw, int tid) {
-    constexpr int M = N / R;
-    constexpr int TOT = L * M;
-    constexpr int ITERS = (TOT + NT - 1) / NT;
-    constexpr bool EXACT = (TOT % NT) == 0;
-    float2 v[ITERS][R];
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int b = tid + it * NT;
-        if (EXACT || b < TOT) {
-            const int line = b / M, j = b - line * M;
-            const float2* p = lds + line * PITCH + j;
-#pragma unroll
-            for (int q = 0; q < R; ++q) v[it][q] = p[q * M];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < ITERS; ++it) {
-        const int b = tid + it * NT;
-        if (EXACT || b < TOT) {
-            const int line = b / M, j = b - line * M;
-            const int k = j % NS;
-            if (NS > 1) {
-                const int idx = k * (N / (NS * R));
-#pragma unroll
-                for (int q = 1; q < R; ++q) {
-                    const float2 w = tw[q * idx];
-                    v[it][q] = INV ? cmulc(v[it][q], w) : cmul(v[it][q], w);
-                }
-            }
-            Radix<R, INV>::run(v[it]);
-            float2* p = lds + line * PITCH + (j / NS) * (NS * R) + k;
-#pragma unroll
-            for (int q = 0; q < R; ++q) p[q * NS] = v[it][q];
-        }
-    }
-    __syncthreads();
-}
-
-template <int N, int NS, int L, int NT, int PITCH, bool INV>
-__device__ __forceinline__ void fft_passes(float2* lds, const float2* tw, int tid) {
-    if constexpr (NS < N) {
-        constexpr int R = pick_radix(N / NS);
-        fft_pass<N, R, NS, L, NT, PITCH, INV>(lds, tw, tid);
-        fft_passes<N, NS * R, L, NT, PITCH, INV>(lds, tw, tid);
-    }
-}
-
-// In-place unnormalised FFT of L lines of N complex points held in LDS (entry/exit: data visible
-// to the whole workgroup, i.e. callers must __syncthreads() after filling `lds`; the last pass syncs).
-template <int N, int L, int NT, int PITCH, bool INV>
-__device__ __forceinline__ void line_fft(float2* lds, const float2* tw, int tid) {
-    fft_passes<N, 1, L, NT, PITCH, INV>(lds, tw, tid);
-}
 
 }  // namespace kcc

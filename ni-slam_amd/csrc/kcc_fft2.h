@@ -115,6 +115,11 @@ template <> struct PlanFor<320> : Plan<320, 16, 20> {};
 template <> struct PlanFor<480> : Plan<480, KCC_P480> {};
 template <> struct PlanFor<640> : Plan<640, KCC_P640> {};
 template <> struct PlanFor<1280> : Plan<1280, 8, 10, 16> {};
+// reference configs/config_geekplus.yaml (448 x 448) and configs/config_HD.yaml (1600 x 1200)
+template <> struct PlanFor<224> : Plan<224, 14, 16> {};
+template <> struct PlanFor<448> : Plan<448, 7, 8, 8> {};
+template <> struct PlanFor<600> : Plan<600, 24, 25> {};
+template <> struct PlanFor<1600> : Plan<1600, 10, 10, 16> {};
 
 // Plan used by the spectrum-in (inverse) A-type kernels; may differ from PlanFor (their tile width, hence their
 // thread budget, differs).  Default: the same plan.

@@ -18,8 +18,8 @@ namespace kcc {
 // ------------------------------------------------------------------------------------------------
 // instantiated FFT lengths (plans: kcc_fft2.h PlanFor<>)
 // ------------------------------------------------------------------------------------------------
-#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(240) X(360)
-#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(480) X(640) X(1280)
+#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(224) X(240) X(360) X(600)
+#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(448) X(480) X(640) X(1280) X(1600)
 
 bool fft_half_supported(int h) {
 #define X(n) if (h == n) return true;
@@ -255,7 +255,7 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int S
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
-template <int HH> using FCfg = ACfg<HH, KCC_ALX, false>;            // forward (real -> spectrum) kernels
+template <int HH> using FCfg = ACfg<HH, (HH > 360 ? 8 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
 template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (spectrum -> ...) kernels
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
@@ -551,11 +551,17 @@ int argmax_blocks(PlaneGeom g) { return g.cols / a_lx(g.rows / 2); }
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
     a.n_items = n_items;
     dim3 grid((a.cols / FCfg<HH>::LX) * n_items), block(FCfg<HH>::NT);
+    static const bool big_lds = (FCfg<HH>::BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_fwd<HH, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FCfg<HH>::BYTES) == hipSuccess);
+    (void)big_lds;
     hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, FCfg<HH>::BYTES, s, a);
 }
 template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
     a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
     dim3 grid((a.cols / ICfg<HH>::LX) * n_items * nz), block(ICfg<HH>::NT);
+    static const bool big_lds = (ICfg<HH>::BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ICfg<HH>::BYTES) == hipSuccess);
+    (void)big_lds;
     hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ICfg<HH>::BYTES, s, a);
 }
 
@@ -570,8 +576,10 @@ static AArgs base_args(PlaneGeom g, Tables t) {
         case 30:  { CALL(30);  break; }   \
         case 60:  { CALL(60);  break; }   \
         case 120: { CALL(120); break; }   \
+        case 224: { CALL(224); break; }   \
         case 240: { CALL(240); break; }   \
         case 360: { CALL(360); break; }   \
+        case 600: { CALL(600); break; }   \
         default: break;                   \
     }
 
@@ -794,9 +802,11 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
         case 80:   { CALL(80);   break; }  \
         case 160:  { CALL(160);  break; }  \
         case 320:  { CALL(320);  break; }  \
+        case 448:  { CALL(448);  break; }  \
         case 480:  { CALL(480);  break; }  \
         case 640:  { CALL(640);  break; }  \
         case 1280: { CALL(1280); break; }  \
+        case 1600: { CALL(1600); break; }  \
         default: break;                    \
     }
 

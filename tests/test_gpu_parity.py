@@ -324,3 +324,48 @@ def test_rgb_1280x720_parity():
         ok, _, msg = check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], 720)
         assert ok, "pair %d %s: %s" % (i, motions[i], msg)
     cf.close()
+
+
+@pytest.mark.parametrize("H,W", [(448, 448), (1200, 1600), (720, 1280), (240, 320)], ids=["448x448", "1600x1200", "1280x720", "320x240"])
+def test_other_reference_geometries(H, W):
+    """the sizes of the reference's other shipped configs (config_geekplus.yaml, config_HD.yaml: radix 7 and 5^2),
+    the config-4 size and a pyramid level; polar 720 x 480 as shipped."""
+    geom = dict(H=H, W=W, PD=720, PC=480)
+    n = 2
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
+    keys, curs, motions = synth.make_batch(n, H, W, seed0=1300 + H, max_shift=min(H, W) // 12, max_theta=8.0)
+    x = np.random.default_rng(H).random((W, H), dtype=np.float32)
+    assert _relmax(cf.dbg_fft(x, 0), orc.fft(x)) < 3e-6
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), True)
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True, nthreads=n)
+    for i in range(n):
+        ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], 720)
+        assert ok, "pair %d %s: %s" % (i, motions[i], msg)
+    cf.close()
+
+
+def test_batch_shapes_and_stream_counts_agree():
+    """results do not depend on batch size, chunking across streams, or the XCD-swizzle tail (n not a multiple of 8)"""
+    geom = SMALL
+    n = 13
+    cf, orc, ocfg = _mk(geom, max_batch=16, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 1500)
+    import torch
+    dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
+    torch.cuda.synchronize()
+    cf.intermedium_batch_dev(dk.data_ptr(), n, list(range(n)))
+    base = None
+    for streams in (1, 2, 3, 4):
+        cf.set_streams(streams)
+        res = cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)
+        got = [r.as_dict() for r in res]
+        if base is None:
+            base = got
+        assert got == base, "streams=%d" % streams
+    for i in (0, 7, 12):                                   # one pair at a time gives the same bits
+        assert cf.pose(i, n + i, True)[2] == base[i]
+    assert cf.pose_batch([], [], True) == []
+    cf.close()
