@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated (tiled to --batch)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--sequence", type=int, default=0, help="also report the tracker on a synthetic sequence of this many "
+                    "frames (extra key `sequence`; not the headline metric)")
     args = ap.parse_args()
 
     import numpy as np
@@ -177,6 +179,27 @@ def main():
                               "frac_of_8TBps": round(pairs_per_s / world * BYTES_PER_PAIR / HBM_PEAK, 4)},
             "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": bool(parity_ok), "kernels": kernels,
         }
+        if args.sequence > 0:
+            # configs[1] as a real sequence: the C++ tracker (MapBuilder tracking subset) with speculative batches;
+            # frames between keyframe switches are registered once, the tail after a switch is re-registered.
+            cv = synth.canvas(4242, H, W)
+            base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
+            seq = np.stack([base[i % 64] for i in range(args.sequence)])
+            d_seq = torch.from_numpy(seq).to(dev)
+            win = min(B, 64)
+            flow2 = N.CorrelationFlow(cfg, H, W, max_batch=win, max_frames=args.sequence + win + 2, device=local_rank)
+            trk = N.Tracker(flow2, N.tracker_config())
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            outs = []
+            for b0 in range(0, args.sequence, win):
+                m = min(win, args.sequence - b0)
+                outs += trk.push_dev(d_seq[b0:b0 + m].data_ptr(), m)
+            dt_seq = time.perf_counter() - t1
+            out["sequence"] = {"frames": args.sequence, "window": win, "frames_per_s": round(args.sequence / dt_seq, 1),
+                               "keyframes": int(sum(o["inserted"] for o in outs)),
+                               "good_tracking": int(sum(o["good_tracking"] for o in outs))}
+            trk.close(); flow2.close()
         print(json.dumps(out))
     cf.close()
     if world > 1:
