@@ -260,76 +260,97 @@ template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (s
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
+// r2c split of one (k, h-k) pair of one line: Z -> X[k], X[h-k]
+__device__ __forceinline__ void r2c_pair(float2 za, float2 zb, float2 w, float2& xk, float2& xh) {
+    const float2 b = cconj(zb);
+    const float2 e = make_float2(0.5f * (za.x + b.x), 0.5f * (za.y + b.y));
+    const float2 d = make_float2(0.5f * (za.x - b.x), 0.5f * (za.y - b.y));
+    const float2 t = cmul(w, make_float2(d.y, -d.x));                         // w^k * (-i d)
+    xk = cadd(e, t); xh = cconj(csub(e, t));
+}
+// c2r merge of one (k, h-k) pair of one line: X[k], X[h-k] -> Z'[k], Z'[h-k]
+__device__ __forceinline__ void c2r_pair(float2 xa, float2 xb, float2 w, float2& zk, float2& zh) {
+    const float2 b = cconj(xb);
+    const float2 sm = cadd(xa, b), d = csub(xa, b);
+    const float2 u = cmulc(d, w);                                             // conj(w^k) * d
+    const float2 iu = make_float2(-u.y, u.x);
+    zk = cadd(sm, iu); zh = cconj(csub(sm, iu));
+}
+
+// natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
+// A thread owns the (k, h-k) pair of TWO adjacent lines: every global access is 16 bytes per lane (8 lanes cover a
+// 128-byte row segment), and all LDS / twiddle reads are issued before the arithmetic.
 template <class C>
 __device__ __forceinline__ void a_post_store(const float2* nat, const float2* __restrict__ tw_full,
                                              float2* __restrict__ spec, int cols, int x0, int tid) {
     constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
-    constexpr int A_LX = C::LX;
-    constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
-    float2 va[ITERS], vb[ITERS], w[ITERS];
+    constexpr int LX2 = C::LX / 2;
+    constexpr int TOT = LX2 * NP, ITERS = (TOT + NT - 1) / NT;
+    float2 va[ITERS][2], vb[ITERS][2], w[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         if (idx < TOT) {
-            const int xx = idx % A_LX, k = idx / A_LX;
-            va[it] = nat[xx * NPITCH + k]; vb[it] = nat[xx * NPITCH + (k ? HH - k : 0)]; w[it] = tw_full[k];
+            const int x2 = idx % LX2, k = idx / LX2, kb = k ? HH - k : 0;
+            const float2* L0 = nat + (2 * x2) * NPITCH; const float2* L1 = L0 + NPITCH;
+            va[it][0] = L0[k]; va[it][1] = L1[k]; vb[it][0] = L0[kb]; vb[it][1] = L1[kb]; w[it] = tw_full[k];
         }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         if (idx < TOT) {
-            const int xx = idx % A_LX, k = idx / A_LX;
-            float2* g = spec + x0 + xx;
+            const int x2 = idx % LX2, k = idx / LX2;
+            float4* g = reinterpret_cast<float4*>(spec + x0 + 2 * x2);
+            const size_t rk = (size_t)k * cols / 2, rh = (size_t)(HH - k) * cols / 2;      // rows in float4 units
+            float2 xk[2], xh[2];
             if (k == 0) {
-                const float2 z = va[it];
-                g[0] = make_float2(z.x + z.y, 0.f);
-                g[(size_t)HH * cols] = make_float2(z.x - z.y, 0.f);
+#pragma unroll
+                for (int l = 0; l < 2; ++l) { const float2 z = va[it][l]; xk[l] = make_float2(z.x + z.y, 0.f); xh[l] = make_float2(z.x - z.y, 0.f); }
             } else {
-                const float2 a = va[it], b = cconj(vb[it]);
-                const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-                const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-                const float2 t = cmul(w[it], make_float2(d.y, -d.x));       // w^k * (-i d)
-                g[(size_t)k * cols] = cadd(e, t);
-                if (2 * k != HH) g[(size_t)(HH - k) * cols] = cconj(csub(e, t));
+#pragma unroll
+                for (int l = 0; l < 2; ++l) r2c_pair(va[it][l], vb[it][l], w[it], xk[l], xh[l]);
             }
+            g[rk] = make_float4(xk[0].x, xk[0].y, xk[1].x, xk[1].y);
+            if (2 * k != HH) g[rh] = make_float4(xh[0].x, xh[0].y, xh[1].x, xh[1].y);
         }
     }
 }
-// transposed global load (k-major spectrum) -> c2r merge -> natural-order input of the packed inverse FFT in LDS.
-// All global loads of a thread are issued before the arithmetic.
+// transposed global load (k-major spectrum, 16 bytes per lane) -> c2r merge -> natural-order input of the packed
+// inverse FFT in LDS.  All global loads of a thread are issued before the arithmetic.
 template <class C>
 __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict__ tw_full,
                                            const float2* __restrict__ spec, int cols, int x0, int tid) {
     constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
-    constexpr int A_LX = C::LX;
-    constexpr int TOT = A_LX * NP, ITERS = (TOT + NT - 1) / NT;
-    float2 va[ITERS], vb[ITERS], w[ITERS];
+    constexpr int LX2 = C::LX / 2;
+    constexpr int TOT = LX2 * NP, ITERS = (TOT + NT - 1) / NT;
+    float4 va[ITERS], vb[ITERS]; float2 w[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         if (idx < TOT) {
-            const int xx = idx % A_LX, k = idx / A_LX;
-            const float2* g = spec + x0 + xx;
-            va[it] = g[(size_t)k * cols]; vb[it] = g[(size_t)(HH - k) * cols]; w[it] = tw_full[k];
+            const int x2 = idx % LX2, k = idx / LX2;
+            const float4* g = reinterpret_cast<const float4*>(spec + x0 + 2 * x2);
+            va[it] = g[(size_t)k * cols / 2]; vb[it] = g[(size_t)(HH - k) * cols / 2]; w[it] = tw_full[k];
         }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         if (idx < TOT) {
-            const int xx = idx % A_LX, k = idx / A_LX;
-            float2* L = nat + xx * NPITCH;
-            if (k == 0) {
-                const float xa = va[it].x, xh = vb[it].x;                    // imag of DC / Nyquist ignored (FFTW c2r)
-                L[0] = make_float2(xa + xh, xa - xh);
+            const int x2 = idx % LX2, k = idx / LX2;
+            float2* L0 = nat + (2 * x2) * NPITCH; float2* L1 = L0 + NPITCH;
+            const float2 xa[2] = { make_float2(va[it].x, va[it].y), make_float2(va[it].z, va[it].w) };
+            const float2 xb[2] = { make_float2(vb[it].x, vb[it].y), make_float2(vb[it].z, vb[it].w) };
+            if (k == 0) {                                                     // imag of DC / Nyquist ignored (FFTW c2r)
+                L0[0] = make_float2(xa[0].x + xb[0].x, xa[0].x - xb[0].x);
+                L1[0] = make_float2(xa[1].x + xb[1].x, xa[1].x - xb[1].x);
             } else {
-                const float2 a = va[it], b = cconj(vb[it]);
-                const float2 sm = cadd(a, b), d = csub(a, b);
-                const float2 u = cmulc(d, w[it]);                             // conj(w^k) * d
-                const float2 iu = make_float2(-u.y, u.x);
-                L[k] = cadd(sm, iu);
-                if (2 * k != HH) L[HH - k] = cconj(csub(sm, iu));
+                float2 zk[2], zh[2];
+#pragma unroll
+                for (int l = 0; l < 2; ++l) c2r_pair(xa[l], xb[l], w[it], zk[l], zh[l]);
+                L0[k] = zk[0]; L1[k] = zk[1];
+                if (2 * k != HH) { L0[HH - k] = zh[0]; L1[HH - k] = zh[1]; }
             }
         }
     }
