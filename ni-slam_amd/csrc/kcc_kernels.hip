@@ -255,7 +255,7 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int S
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
-template <int HH> using FCfg = ACfg<HH, (HH > 360 ? 8 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
+template <int HH> using FCfg = ACfg<HH, (HH >= 360 ? 8 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
 template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (spectrum -> ...) kernels
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
@@ -696,7 +696,9 @@ template <int N> struct BCfg {
     static constexpr int LK = (T >= 128) ? 2 : (T >= 64 ? 4 : (T >= 20 ? 8 : 16));     // lines per workgroup
     static constexpr int NT = LK * T;
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
-    static constexpr size_t BYTES = (size_t)2 * LK * EPITCH * sizeof(float2);             // two exchange buffers per line
+    // exchange buffers per line: two for the modes that transform two planes at once, else one
+    static constexpr int nv(int mode) { return (mode == 2 || mode == 3 || mode == 4) ? 2 : 1; }
+    static constexpr size_t bytes(int mode) { return (size_t)nv(mode) * LK * EPITCH * sizeof(float2); }
 };
 
 template <int RR>
@@ -732,8 +734,9 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
     const bool vst = valid0 && !(a.ablate & 2);            // stores
     const bool nofft = a.ablate & 4;
     const size_t loff = (size_t)k * N + j;
-    float2* const ex1[1] = { lds + (2 * lk) * C::EPITCH };
-    float2* const ex2[2] = { lds + (2 * lk) * C::EPITCH, lds + (2 * lk + 1) * C::EPITCH };
+    constexpr int NVM = C::nv(MODE);
+    float2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
+    float2* const ex2[2] = { lds + (NVM * lk) * C::EPITCH, lds + (NVM * lk + NVM - 1) * C::EPITCH };
 
     if (MODE == B_FWD || MODE == B_INV) {
         constexpr bool INV = (MODE == B_INV);
@@ -812,10 +815,11 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
 template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a) {
     constexpr int LK = BCfg<N>::LK;
     dim3 grid((a.hr + LK - 1) / LK, n_items), block(BCfg<N>::NT);
-    static const bool big_lds = (BCfg<N>::BYTES > 65536) &&
-        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BCfg<N>::BYTES) == hipSuccess);
+    constexpr size_t BYTES = BCfg<N>::bytes(MODE);
+    static const bool big_lds = (BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES) == hipSuccess);
     (void)big_lds;
-    hipLaunchKernelGGL((kB<N, MODE>), grid, block, BCfg<N>::BYTES, s, a);
+    hipLaunchKernelGGL((kB<N, MODE>), grid, block, BYTES, s, a);
 }
 
 #define DISPATCH_LINE(n, CALL)             \
