@@ -86,6 +86,11 @@ void* nik_stream(const nik_ctx* ctx);
  * returns the number now active.  Outputs do not depend on it. */
 int  nik_set_streams(nik_ctx* ctx, int n);
 int  nik_synchronize(nik_ctx* ctx);
+/* Per-keyframe cache of the key-side kernel Kzz = FFT(kernel(IFFT(|Z|^2))) and its max (both families), built the
+ * first time a slot is used as a key and dropped when the slot is rewritten.  The reference recomputes Kzz in every
+ * EstimateTrans call (correlation_flow.cc:160,164) although it depends on the keyframe only; outputs are identical.
+ * Default off ($NIK_KZZ_CACHE=1 turns it on at creation); costs (H/2+1)*W + (PD/2+1)*PC complex per slot. */
+int  nik_set_kzz_cache(nik_ctx* ctx, int enable);
 
 /* ---- ComputeIntermedium (correlation_flow.cc:89-95) ------------------------------------- */
 

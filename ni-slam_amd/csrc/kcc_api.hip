@@ -78,6 +78,10 @@ struct nik_ctx {
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
     float* arena_img = nullptr; float2* arena_F = nullptr; float2* arena_P = nullptr;
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
+    // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
+    bool kzz_cache = false;
+    float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
+    std::vector<uint8_t> slot_kzz;       // 1: cache valid
     std::vector<int8_t> slot_lane;       // lane that last wrote the slot (-1: none / host import)
     std::vector<unsigned long> slot_seq; // that lane's write_seq at the time
     std::vector<unsigned long> slot_rd;  // [slot][4]: call_seq of each lane's latest call that read the slot
@@ -368,7 +372,7 @@ int depend_for_write(nik_ctx* c, Lane& L, int li, nik_frame f) {
 int mark_written(nik_ctx* c, Lane& L, int li, const int* slots, int n) {
     L.write_seq += 1;
     HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
-    for (int i = 0; i < n; ++i) { c->slot_lane[slots[i]] = (int8_t)li; c->slot_seq[slots[i]] = L.write_seq; c->slot_ready[slots[i]] = 3; }
+    for (int i = 0; i < n; ++i) { c->slot_lane[slots[i]] = (int8_t)li; c->slot_seq[slots[i]] = L.write_seq; c->slot_ready[slots[i]] = 3; c->slot_kzz[slots[i]] = 0; }
     return NIK_OK;
 }
 
@@ -424,12 +428,26 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
     if (c->cfg.kernel == 1 && !x_fwd)
         launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
+    const bool cached = c->kzz_cache;
+    if (cached) {
+        // key-side kernel Kzz comes from the slot cache (ensure_kzz ran before): only the xz half is computed
+        float2* kz = (&f == &c->pol) ? c->arena_KzP : c->arena_KzF;
+        unsigned* mz = (&f == &c->pol) ? c->arena_MzP : c->arena_MzF;
+        { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv_x" : "mul_inv_x").c_str(), n * 3 * Cb(f));
+          launch_B_mul_inv_x(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf); }
+        { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_x").c_str(), n * 2 * Cb(f));
+          launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 1, 1); }
+        { Stage st(c, L, kname("kB", f.g.cols, "solve_cached").c_str(), n * 3 * Cb(f));
+          launch_B_solve_cached(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, kz, f.spec_elems, mz, z_idx,
+                                c->cfg.lambda, L.gbuf, c->spec_max); }
+    } else {
     { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
       launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf); }
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
       launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy); }
     { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
       launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max); }
+    }
     const int nb = argmax_blocks(f.g);
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
       launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
@@ -569,6 +587,12 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img.real_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
+    TRY_C(hipMalloc(&c->arena_KzF, sizeof(float2) * c->img.spec_elems * max_frames));
+    TRY_C(hipMalloc(&c->arena_KzP, sizeof(float2) * c->pol.spec_elems * max_frames));
+    TRY_C(hipMalloc(&c->arena_MzF, sizeof(unsigned) * max_frames));
+    TRY_C(hipMalloc(&c->arena_MzP, sizeof(unsigned) * max_frames));
+    c->slot_kzz.assign(max_frames, 0);
+    if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 2;
     if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);
@@ -589,6 +613,7 @@ void nik_destroy(nik_ctx* c) {
     for (Lane& L : c->lanes) lane_free(L);
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
+    (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->rot_tab);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
@@ -610,6 +635,14 @@ int nik_set_streams(nik_ctx* c, int n) {
     if (rc) return rc;
     c->active_lanes = std::max(1, std::min((int)c->lanes.size(), n));
     return c->active_lanes;
+}
+
+int nik_set_kzz_cache(nik_ctx* c, int enable) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    c->kzz_cache = enable != 0;
+    return NIK_OK;
 }
 
 int nik_synchronize(nik_ctx* c) {
@@ -710,7 +743,52 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
     }
     HIP_TRY(c, hipStreamSynchronize(s));
     c->slot_lane[f] = -1;                                   // host-synchronous write: visible to every lane
+    c->slot_kzz[f] = 0;
     if (fft_result && fft_polar) c->slot_ready[f] |= 2;
+    return NIK_OK;
+}
+
+// Build the Kzz cache of every listed key slot that lacks it (both families), on lane 0:
+//   Kzz' = FFT( kernel( IFFT(|Z|^2) ) ) (not yet divided by its max) and Mzz = max|kernel|   (correlation_flow.cc:160,164)
+static int ensure_kzz(nik_ctx* c, int n, const nik_frame* keys) {
+    std::vector<nik_frame> todo;
+    for (int i = 0; i < n; ++i)
+        if (!c->slot_kzz[keys[i]]) { c->slot_kzz[keys[i]] = 2; todo.push_back(keys[i]); }      // 2 = scheduled in this pass
+    if (todo.empty()) return NIK_OK;
+    Lane& L = c->lanes[0];
+    int rc;
+    for (size_t b = 0; b < todo.size(); b += (size_t)c->max_batch) {
+        const int m = (int)std::min(todo.size() - b, (size_t)c->max_batch);
+        if ((rc = begin_call(c, L))) return rc;
+        for (int i = 0; i < m; ++i) {
+            if ((rc = depend_on_slot(c, L, 0, todo[b + i]))) return rc;
+            note_read(c, L, 0, todo[b + i]);
+            hidx(L, IX_KEY)[i] = todo[b + i];
+        }
+        if ((rc = upload_idx(c, L, IX_KEY, m))) return rc;
+        const size_t item_stride = 2 * c->spec_max;
+        for (int fam = 0; fam < 2; ++fam) {
+            Family& f = fam ? c->img : c->pol;
+            const float2* zsrc = fam ? c->arena_F : c->arena_P;
+            float2* kz = fam ? c->arena_KzF : c->arena_KzP;
+            unsigned* mz = fam ? c->arena_MzF : c->arena_MzP;
+            if (c->cfg.kernel == 1)
+                launch_energy(L.stream, m, f.g, zsrc, f.spec_elems, didx(L, IX_KEY), zsrc, f.spec_elems, didx(L, IX_KEY), L.energy);
+            { Stage st(c, L, kname("kB", f.g.cols, "zz_inv").c_str(), m * 2 * Cb(f));
+              launch_B_zz_inv(L.stream, m, f.g, f.t, zsrc, f.spec_elems, didx(L, IX_KEY), L.kbuf, item_stride, L.maxbuf); }
+            { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_z").c_str(), m * 2 * Cb(f));
+              launch_A_inv_kernel_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, c->spec_max, kernel_fn(c), L.maxbuf, L.energy, 0, 1); }
+            { Stage st(c, L, kname("kB", f.g.cols, "fwd_kzz").c_str(), m * 2 * Cb(f));
+              launch_B_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, kz, f.spec_elems, didx(L, IX_KEY)); }
+            launch_store_mzz(L.stream, m, L.maxbuf, didx(L, IX_KEY), mz);
+        }
+        HIP_TRY(c, hipGetLastError());
+        // publish as a slot write of lane 0 so that other lanes order their reads after it
+        L.write_seq += 1;
+        HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
+        for (int i = 0; i < m; ++i) { c->slot_lane[todo[b + i]] = 0; c->slot_seq[todo[b + i]] = L.write_seq; c->slot_kzz[todo[b + i]] = 1; }
+        if ((rc = end_call(c, L))) return rc;
+    }
     return NIK_OK;
 }
 
@@ -718,6 +796,7 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
 static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* keys, const nik_frame* curs,
                      int not_large_rotation, nik_pose_result* res) {
     int rc;
+    if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
     for (int li = 0; li < nl; ++li) {
         int b, e; chunk_of(n, nl, li, b, e);

@@ -90,7 +90,8 @@ void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
 // buf holds 2 planes per item (zz then xz), maxbuf 2 uints per item (float bits, zeroed by caller),
 // energy 2 floats per item (gaussian: sum|X|^2, sum|Z|^2 over the half spectrum).
 void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, float2* buf, size_t item_stride,
-                             size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy);
+                             size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy,
+                             int plane_first = 0, int n_planes = 2);
 // inverse -> /(rows*cols) -> arg-max + moments partials
 void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                          Partial* partials, int partial_stride);
@@ -114,6 +115,21 @@ void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_
 // G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride);
+
+// ---- per-keyframe Kzz cache (SURVEY 8d "with Kzz cached"): the zz / xz halves of the kernel stage on their own
+// plane 0 := inv(|Z|^2)
+void launch_B_zz_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* zsrc, size_t z_stride, const int* z_idx,
+                     float2* out, size_t item_stride, unsigned* maxbuf_zero);
+// plane 1 := inv(X conj Z)
+void launch_B_mul_inv_x(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
+                        const float2* xsrc, size_t x_stride, const int* x_idx,
+                        const float2* zsrc, size_t z_stride, const int* z_idx,
+                        float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero);
+// G from the cached Kzz spectrum / max of slot z_idx[item] and Kxz = fwd(buf plane 1)
+void launch_B_solve_cached(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
+                           size_t plane_stride, const unsigned* maxbuf, const float2* kzz, size_t kzz_stride,
+                           const unsigned* mzz, const int* z_idx, float lambda, float2* out, size_t out_stride);
+void launch_store_mzz(hipStream_t s, int n, const unsigned* maxbuf, const int* slots, unsigned* mzz);
 
 // half-spectrum energies for the gaussian kernel: energy[item] = {sum|X|^2, sum|Z|^2}
 void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, size_t x_stride, const int* x_idx,

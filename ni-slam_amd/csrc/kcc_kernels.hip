@@ -200,6 +200,7 @@ struct AArgs {
     int H, W, SP; const uint32_t* polar_tab;                 // polar source: shifted planes, column pitch SP
     // spectrum side
     float2* spec; size_t spec_stride; size_t plane_stride;
+    int plane_first, n_planes;                               // kernel_fwd: planes [plane_first, plane_first+n_planes) of each item
     // inverse outputs
     float* real_out; size_t real_stride;
     Partial* partials; int partial_stride;
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     int bx, item2;
     constexpr bool KFWD = epi_is_kfwd(EPI);
     constexpr int KT = EPI == EPI_KFWD_POLY3 ? KT_POLY3 : (EPI == EPI_KFWD_POLYN ? KT_POLYN : KT_GAUSS);
-    xcd_coords(nbx, a.n_items * (KFWD ? 2 : 1), bx, item2);
-    const int item = KFWD ? item2 >> 1 : item2;
-    const int plane = KFWD ? item2 & 1 : 0;
+    xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2);
+    const int item = KFWD ? item2 / a.n_planes : item2;
+    const int plane = KFWD ? a.plane_first + item2 % a.n_planes : 0;
     const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
@@ -646,19 +647,21 @@ void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 #undef CALL
 }
 void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, float2* buf, size_t item_stride,
-                             size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy) {
+                             size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy,
+                             int plane_first, int n_planes) {
     AArgs a = base_args(g, t);
     a.spec = buf; a.spec_stride = item_stride; a.plane_stride = plane_stride; a.fn = fn; a.maxbuf = maxbuf; a.energy = energy;
+    a.plane_first = plane_first; a.n_planes = n_planes;
     if (fn.type == 1) {
-#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_GAUSS>(s, n_items, 2, a)
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_GAUSS>(s, n_items, n_planes, a)
         DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
     } else if (fn.power == 3) {
-#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLY3>(s, n_items, 2, a)
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLY3>(s, n_items, n_planes, a)
         DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
     } else {
-#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLYN>(s, n_items, 2, a)
+#define CALL(HH) launchA_inv_t<HH, EPI_KFWD_POLYN>(s, n_items, n_planes, a)
         DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
     }
@@ -675,7 +678,9 @@ void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, cons
 // ------------------------------------------------------------------------------------------------
 // B-type kernels
 // ------------------------------------------------------------------------------------------------
-enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_INV = 4, B_INV = 5 };
+enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_INV = 4, B_INV = 5,
+       // per-keyframe Kzz cache: zz-only / xz-only halves of the above and the solve that reads the cached Kzz
+       B_ZZ_INV = 6, B_MUL_INV_X = 7, B_FWD_MUL_INV_X = 8, B_SOLVE_CACHED = 9 };
 
 struct BArgs {
     int cols, hr, ablate;
@@ -688,6 +693,7 @@ struct BArgs {
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; float lambda;
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
+    const float2* kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
 };
 
 template <int N> struct BCfg {
@@ -785,6 +791,58 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
             store_strided(o[0], d, DI::ML);
             store_strided(o[1], d + a.out_plane_stride, DI::ML);
         }
+    } else if (MODE == B_ZZ_INV) {
+        // Kzz half of the kernel stage: |Z|^2 -> inverse col FFT (plane 0)
+        float2 zv[1][DI::RF], o[1][DI::RL];
+        if (blockIdx.x == 0 && tid < 1) a.maxbuf_zero[2 * item] = 0u;
+        load_strided(zv[0], a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
+#pragma unroll
+        for (int q = 0; q < DI::RF; ++q) zv[0][q] = make_float2(zv[0][q].x * zv[0][q].x + zv[0][q].y * zv[0][q].y, 0.f);
+        if (!nofft) fft_chain<P, true, 1>(zv, o, j, ex1, a.tw_i);
+        if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
+    } else if (MODE == B_MUL_INV_X || MODE == B_FWD_MUL_INV_X) {
+        // Kxz half: X conj Z -> inverse col FFT (plane 1)
+        float2 pr[1][DI::RF], o[1][DI::RL], zv[DI::RF];
+        if (blockIdx.x == 0 && tid < 1) a.maxbuf_zero[2 * item + 1] = 0u;
+        load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
+        if (MODE == B_FWD_MUL_INV_X) {
+            float2 vin[1][DF::RF], x[1][DF::RL];
+            load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
+            if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+#pragma unroll
+            for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(x[0][q], zv[q]);
+            __syncthreads();
+        } else {
+            float2 xv[DI::RF];
+            load_strided(xv, a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DI::MF, valid && j < DI::MF);
+#pragma unroll
+            for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(xv[q], zv[q]);
+        }
+        if (!nofft) fft_chain<P, true, 1>(pr, o, j, ex1, a.tw_i);
+        if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + a.out_plane_stride + loff, DI::ML);
+    } else if (MODE == B_SOLVE_CACHED) {
+        // as SOLVE_INV, but Kzz (already transformed) and its max come from the key slot's cache
+        float2 vin[1][DF::RF], kx[1][DF::RL], kz[DF::RL], g[1][DI::RF], o[1][DI::RL];
+        const int zslot = a.z_idx[item];
+        load_strided(vin[0], a.src + (size_t)item * a.src_stride + a.in_plane_stride + loff, DF::MF, valid && j < DF::MF);
+        load_strided(kz, a.kzz + (size_t)zslot * a.kzz_stride + loff, DF::ML, valid && j < DF::ML);
+        const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.mzz[zslot]));
+        const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
+        if (!nofft) fft_chain<P, false, 1>(vin, kx, j, ex1, a.tw_f);
+        static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
+        const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
+#pragma unroll
+        for (int q = 0; q < DF::RL; ++q) {
+            const float2 den = make_float2(kz[q].x * rzz + a.lambda, kz[q].y * rzz);
+            const float2 num = make_float2(kx[0][q].x * rxz, kx[0][q].y * rxz);
+            const float inv = sg * __builtin_amdgcn_rcpf(den.x * den.x + den.y * den.y);
+            const float2 gg = cmulc(num, den);
+            g[0][q] = make_float2(gg.x * inv, gg.y * inv);
+        }
+        if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
+        __syncthreads();
+        if (!nofft) fft_chain<P, true, 1>(g, o, j, ex1, a.tw_i);
+        if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     } else {
         // H = T/(Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l)
         float2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
@@ -883,6 +941,48 @@ void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_
         DISPATCH_LINE(g.cols, CALL)
 #undef CALL
     }
+}
+void launch_B_zz_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* zsrc, size_t z_stride, const int* z_idx,
+                     float2* out, size_t item_stride, unsigned* maxbuf_zero) {
+    BArgs a = base_bargs(g, t);
+    a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx; a.dst = out; a.dst_stride = item_stride; a.maxbuf_zero = maxbuf_zero;
+#define CALL(N) launchB_t<N, B_ZZ_INV>(s, n_items, a)
+    DISPATCH_LINE(g.cols, CALL)
+#undef CALL
+}
+void launch_B_mul_inv_x(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
+                        const float2* xsrc, size_t x_stride, const int* x_idx,
+                        const float2* zsrc, size_t z_stride, const int* z_idx,
+                        float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero) {
+    BArgs a = base_bargs(g, t);
+    a.src = xsrc; a.src_stride = x_stride; a.src_idx = x_idx; a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx;
+    a.dst = out; a.dst_stride = item_stride; a.out_plane_stride = plane_stride; a.maxbuf_zero = maxbuf_zero;
+    if (x_fwd) {
+#define CALL(N) launchB_t<N, B_FWD_MUL_INV_X>(s, n_items, a)
+        DISPATCH_LINE(g.cols, CALL)
+#undef CALL
+    } else {
+#define CALL(N) launchB_t<N, B_MUL_INV_X>(s, n_items, a)
+        DISPATCH_LINE(g.cols, CALL)
+#undef CALL
+    }
+}
+void launch_B_solve_cached(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
+                           size_t plane_stride, const unsigned* maxbuf, const float2* kzz, size_t kzz_stride,
+                           const unsigned* mzz, const int* z_idx, float lambda, float2* out, size_t out_stride) {
+    BArgs a = base_bargs(g, t);
+    a.src = buf; a.src_stride = item_stride; a.in_plane_stride = plane_stride; a.maxbuf = maxbuf; a.lambda = lambda;
+    a.kzz = kzz; a.kzz_stride = kzz_stride; a.mzz = mzz; a.z_idx = z_idx; a.dst = out; a.dst_stride = out_stride;
+#define CALL(N) launchB_t<N, B_SOLVE_CACHED>(s, n_items, a)
+    DISPATCH_LINE(g.cols, CALL)
+#undef CALL
+}
+__global__ void k_store_mzz(int n, const unsigned* __restrict__ maxbuf, const int* __restrict__ slots, unsigned* __restrict__ mzz) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mzz[slots[i]] = maxbuf[2 * i];
+}
+void launch_store_mzz(hipStream_t s, int n, const unsigned* maxbuf, const int* slots, unsigned* mzz) {
+    hipLaunchKernelGGL(k_store_mzz, dim3((n + 63) / 64), dim3(64), 0, s, n, maxbuf, slots, mzz);
 }
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride) {

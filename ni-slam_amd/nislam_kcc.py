@@ -25,7 +25,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
-           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
+           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
 
 
 class NikConfig(C.Structure):
@@ -111,6 +111,7 @@ def load():
         L.nik_stream.restype = P
         L.nik_synchronize.argtypes = [P]
         L.nik_set_streams.argtypes = [P, I]
+        L.nik_set_kzz_cache.argtypes = [P, I]
         L.nik_intermedium_u8.argtypes = [P, P, I, I]
         L.nik_intermedium_f32.argtypes = [P, P, I]
         L.nik_intermedium_batch_dev.argtypes = [P, I, P, P]
@@ -179,6 +180,9 @@ class CorrelationFlow:
 
     def synchronize(self):
         self._chk(self._L.nik_synchronize(self._ctx))
+
+    def set_kzz_cache(self, on=True):
+        self._chk(self._L.nik_set_kzz_cache(self._ctx, int(bool(on))))
 
     def set_streams(self, n):
         return self._L.nik_set_streams(self._ctx, int(n))

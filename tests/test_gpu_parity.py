@@ -369,3 +369,50 @@ def test_batch_shapes_and_stream_counts_agree():
         assert cf.pose(i, n + i, True)[2] == base[i]
     assert cf.pose_batch([], [], True) == []
     cf.close()
+
+
+def _same_registration(a, b, rel=2e-5):
+    """identical arg-max indices / pose; PSR equal up to the rounding of differently fused FMAs"""
+    for k in ("pose", "rot_row", "rot_col", "trans_row", "trans_col", "chosen", "n_hyp", "degree_final"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    for x, y in zip(a["info"], b["info"]):
+        assert abs(x - y) <= rel * abs(y)
+
+
+@pytest.mark.parametrize("kernel", [0, 1], ids=["poly", "gauss"])
+def test_kzz_cache_same_results(kernel):
+    """the per-keyframe Kzz cache (SURVEY 8d "Kzz cached") changes the work, not the outputs (same arg-max indices
+    and poses; PSR equal to float rounding: the cached path runs single-plane instantiations of the same kernels,
+    whose FMA contraction differs); the cache is dropped when a slot is rewritten"""
+    geom, n = SMALL, 10
+    cf, orc, ocfg = _mk(geom, kernel=kernel, max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 1700)
+    import torch
+    dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
+    torch.cuda.synchronize()
+    cf.intermedium_batch_dev(dk.data_ptr(), n, list(range(n)))
+    ks, cs = list(range(n)), list(range(n, 2 * n))
+    ref_small = [r.as_dict() for r in cf.track_batch_dev(dc.data_ptr(), ks, cs, True, sync=True)]
+    ref_large = cf.pose_batch(ks, cs, False)
+    cf.set_kzz_cache(True)
+    for rep in range(2):                                  # first pass builds the cache, second one uses it
+        got = [r.as_dict() for r in cf.track_batch_dev(dc.data_ptr(), ks, cs, True, sync=True)]
+        for g, r in zip(got, ref_small):
+            _same_registration(g, r)
+        for g, r in zip(cf.pose_batch(ks, cs, False), ref_large):
+            _same_registration(g, r)
+        if rep == 1:
+            assert got == first                           # cached passes are deterministic
+        first = got
+    # shared key (the tracker's pattern) and loop closure use the same cache
+    same = cf.pose_batch([3] * n, cs, True)
+    cf.set_kzz_cache(False)
+    for g, r in zip(cf.pose_batch([3] * n, cs, True), same):
+        _same_registration(g, r)
+    cf.set_kzz_cache(True)
+    # rewriting a key slot invalidates its cache: slot 0 now holds a different image
+    cf.intermedium_u8(curs[5], 0)
+    a = cf.pose(0, n + 1, True)[2]
+    cf.set_kzz_cache(False)
+    _same_registration(cf.pose(0, n + 1, True)[2], a)
+    cf.close()
