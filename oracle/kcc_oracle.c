@@ -9,6 +9,7 @@
  */
 #include "kcc_oracle.h"
 
+#include <malloc.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,17 +65,12 @@ static void plan_init(ora_plan* p, int n) {
     }
 }
 
+/* a context is single-owner (not thread-safe), like the reference's CorrelationFlow: no locking */
 static const ora_plan* get_plan(ora_ctx* ctx, int n) {
-    const ora_plan* found = NULL;
-    #pragma omp critical(ora_plan_cache)
-    {
-        for (int i = 0; i < ctx->nplans; ++i) if (ctx->plans[i].n == n) { found = &ctx->plans[i]; break; }
-        if (!found && ctx->nplans < ORA_MAX_PLANS) {
-            plan_init(&ctx->plans[ctx->nplans], n);
-            found = &ctx->plans[ctx->nplans++];
-        }
-    }
-    return found;
+    for (int i = 0; i < ctx->nplans; ++i) if (ctx->plans[i].n == n) return &ctx->plans[i];
+    if (ctx->nplans >= ORA_MAX_PLANS) return NULL;
+    plan_init(&ctx->plans[ctx->nplans], n);
+    return &ctx->plans[ctx->nplans++];
 }
 
 /* One Stockham autosort pass of radix r (Ns = product of the radices already applied). */
@@ -617,6 +613,9 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
                     double* poses, double* infos, ora_pose_debug* dbgs, double* seconds_unit) {
     int rc = 0; double t_total = 0;
     if (nthreads < 1) nthreads = 1;
+    /* plane-sized temporaries are malloc'ed per call (as the reference's Eigen temporaries are): keep them on the
+       per-thread heaps instead of mmap/munmap, whose kernel lock serialises many threads */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30); mallopt(M_TRIM_THRESHOLD, 1 << 30); mallopt(M_ARENA_MAX, 512);
 #ifdef _OPENMP
     omp_set_num_threads(nthreads);
 #endif
