@@ -55,7 +55,7 @@ PlanDesc plan_desc(int n_) {
 #ifndef KCC_ALX
 #define KCC_ALX 16
 #endif
-int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT
+int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT, 8 exit at once (dispatch cost only)
 void set_ablate(int f) { g_ablate = f; }
 
 // lines per A-type workgroup: 16 float2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
@@ -256,7 +256,10 @@ __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int S
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
-template <int HH> using FCfg = ACfg<HH, (HH >= 360 ? 8 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
+#ifndef KCC_FLX360
+#define KCC_FLX360 16
+#endif
+template <int HH> using FCfg = ACfg<HH, (HH >= 360 ? KCC_FLX360 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
 template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (spectrum -> ...) kernels
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
@@ -365,6 +368,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     float2* lds = reinterpret_cast<float2*>(smem);
+    if (a.ablate & 8) return;
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
     int bx, item;
     constexpr int A_LX = C::LX;
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     using C = ICfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
+    if (a.ablate & 8) return;
     __shared__ float red_f[NW];
     __shared__ int red_i[NW];
     __shared__ double red_d[2][NW];
@@ -733,6 +738,7 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
     using C = BCfg<N>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
     static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
     float2* lds = reinterpret_cast<float2*>(smem);
+    if (a.ablate & 8) return;
     const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
     const int item = blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
     const bool valid0 = k < a.hr;
