@@ -701,15 +701,29 @@ struct BArgs {
     const float2* kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
 };
 
-template <int N> struct BCfg {
+// lines per workgroup: fewer for the modes that hold two planes' exchange buffers (LDS-limited occupancy)
+#ifndef KCC_BLK_MID
+#define KCC_BLK_MID 8
+#endif
+#ifndef KCC_BLK_MID2
+#define KCC_BLK_MID2 5
+#endif
+#ifndef KCC_BLK_BIG
+#define KCC_BLK_BIG 4
+#endif
+#ifndef KCC_BLK_BIG2
+#define KCC_BLK_BIG2 3
+#endif
+template <int N, int MODE> struct BCfg {
     using P = PlanFor<N>;
     static constexpr int T = P::T;
-    static constexpr int LK = (T >= 128) ? 2 : (T >= 64 ? 4 : (T >= 20 ? 8 : 16));     // lines per workgroup
+    // exchange buffers per line: two for the modes that transform two planes at once, else one
+    static constexpr int NV = (MODE == 2 || MODE == 3 || MODE == 4) ? 2 : 1;
+    static constexpr int LK = (T >= 128) ? 2 : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
+                                                        : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
     static constexpr int NT = LK * T;
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
-    // exchange buffers per line: two for the modes that transform two planes at once, else one
-    static constexpr int nv(int mode) { return (mode == 2 || mode == 3 || mode == 4) ? 2 : 1; }
-    static constexpr size_t bytes(int mode) { return (size_t)nv(mode) * LK * EPITCH * sizeof(float2); }
+    static constexpr size_t BYTES = (size_t)NV * LK * EPITCH * sizeof(float2);
 };
 
 template <int RR>
@@ -733,9 +747,9 @@ __device__ __forceinline__ void store_strided(const float2 (&v)[RR], float2* __r
 }
 
 template <int N, int MODE>
-__global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
+__global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = BCfg<N>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
+    using C = BCfg<N, MODE>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
     static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
     float2* lds = reinterpret_cast<float2*>(smem);
     if (a.ablate & 8) return;
@@ -746,7 +760,7 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
     const bool vst = valid0 && !(a.ablate & 2);            // stores
     const bool nofft = a.ablate & 4;
     const size_t loff = (size_t)k * N + j;
-    constexpr int NVM = C::nv(MODE);
+    constexpr int NVM = C::NV;
     float2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
     float2* const ex2[2] = { lds + (NVM * lk) * C::EPITCH, lds + (NVM * lk + NVM - 1) * C::EPITCH };
 
@@ -877,9 +891,9 @@ __global__ __launch_bounds__(BCfg<N>::NT) void kB(BArgs a) {
 }
 
 template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a) {
-    constexpr int LK = BCfg<N>::LK;
-    dim3 grid((a.hr + LK - 1) / LK, n_items), block(BCfg<N>::NT);
-    constexpr size_t BYTES = BCfg<N>::bytes(MODE);
+    constexpr int LK = BCfg<N, MODE>::LK;
+    dim3 grid((a.hr + LK - 1) / LK, n_items), block(BCfg<N, MODE>::NT);
+    constexpr size_t BYTES = BCfg<N, MODE>::BYTES;
     static const bool big_lds = (BYTES > 65536) &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES) == hipSuccess);
     (void)big_lds;
