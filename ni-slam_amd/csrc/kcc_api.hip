@@ -80,6 +80,7 @@ struct nik_ctx {
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
     // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
     bool kzz_cache = false;
+    bool fuse_polar = true;       // tracking path: fuse the polar spectrum's last pass into the pose's first kernel ($NIK_FUSE_POLAR=0: off)
     float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
     std::vector<uint8_t> slot_kzz;       // 1: cache valid
     std::vector<int8_t> slot_lane;       // lane that last wrote the slot (-1: none / host import)
@@ -403,7 +404,10 @@ inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // 
 
 // ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
 // arena slots listed in d_idx[IX_DST].
-void enqueue_intermedium(nik_ctx* c, Lane& L, int n) {
+// defer_polar_B: leave the polar spectrum's second (radius) pass to the caller -- the pose that follows fuses it into
+// its first kernel (fwd_mul_inv), which also writes the finished spectrum to the frame store.  L.tmpA then holds the
+// half-transformed polar spectra.
+void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false) {
     hipStream_t s = L.stream;
     const int* dst = didx(L, IX_DST);
     const Family& I = c->img; const Family& P = c->pol;
@@ -417,14 +421,17 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n) {
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
     { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
       launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab, L.tmpA, c->spec_max); }
+    if (defer_polar_B) return;
     { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
 }
 
 // EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
 void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const float2* xsrc, size_t x_stride, const int* x_idx,
-                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out, int* rot_index, int n_hyp) {
+                      const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out, int* rot_index, int n_hyp,
+                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr) {
     hipStream_t s = L.stream;
+    const double xs_bytes = xstore ? n * Cb(f) : 0.0;        // x_fwd with xstore: the forward spectrum is written out too
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
     if (c->cfg.kernel == 1 && !x_fwd)
         launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
@@ -433,16 +440,18 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
         // key-side kernel Kzz comes from the slot cache (ensure_kzz ran before): only the xz half is computed
         float2* kz = (&f == &c->pol) ? c->arena_KzP : c->arena_KzF;
         unsigned* mz = (&f == &c->pol) ? c->arena_MzP : c->arena_MzF;
-        { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv_x" : "mul_inv_x").c_str(), n * 3 * Cb(f));
-          launch_B_mul_inv_x(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf); }
+        { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv_x" : "mul_inv_x").c_str(), n * 3 * Cb(f) + xs_bytes);
+          launch_B_mul_inv_x(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
+                             xstore, xstore_stride, xstore_slot); }
         { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_x").c_str(), n * 2 * Cb(f));
           launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 1, 1); }
         { Stage st(c, L, kname("kB", f.g.cols, "solve_cached").c_str(), n * 3 * Cb(f));
           launch_B_solve_cached(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, kz, f.spec_elems, mz, z_idx,
                                 c->cfg.lambda, L.gbuf, c->spec_max); }
     } else {
-    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f));
-      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf); }
+    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f) + xs_bytes);
+      launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
+                       xstore, xstore_stride, xstore_slot); }
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
       launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy); }
     { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
@@ -456,10 +465,17 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
 
 // ComputePose (correlation_flow.cc:97-143) for n pairs; key/cur slots in the lane's IX_KEY / IX_CUR arrays.
 // Leaves raw surface results in the call's h_rot / h_trans (valid after its `done` event).
-int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation) {
+// polar_in_tmpA: the current frames' polar spectra are still half-transformed in L.tmpA (enqueue_intermedium with
+// defer_polar_B): the rotation stage finishes them, stores them in the frame store (slots IX_DST) and uses them.
+int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_in_tmpA = false) {
     hipStream_t s = L.stream;
     const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
     // rotation stage: z = key polar spectrum, x = current polar spectrum
+    if (polar_in_tmpA)
+        enqueue_estimate(c, L, n, c->pol, true, L.tmpA, c->spec_max, nullptr,
+                         c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp,
+                         c->arena_P, c->pol.spec_elems, didx(L, IX_DST));
+    else
     enqueue_estimate(c, L, n, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
                      c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
@@ -593,6 +609,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     TRY_C(hipMalloc(&c->arena_MzP, sizeof(unsigned) * max_frames));
     c->slot_kzz.assign(max_frames, 0);
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
+    if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 2;
     if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);
@@ -810,13 +827,17 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             else { if ((rc = depend_on_slot(c, L, li, curs[i]))) return rc; note_read(c, L, li, curs[i]); }
         }
         if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
+        bool fuse = false;
         if (d_gray) {
             { Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
               launch_cvt_u8(L.stream, m, d_gray + (size_t)b * c->img.real_elems, didx(L, IX_DST), c->arena_img, c->H, c->W); }
-            enqueue_intermedium(c, L, m);
+            // the polar spectrum's last pass is fused into the pose's first kernel (not for the gaussian kernel,
+            // which needs sum|X|^2 of the finished spectrum before that kernel runs)
+            fuse = (c->cfg.kernel != 1) && c->fuse_polar;
+            enqueue_intermedium(c, L, m, fuse);
             if ((rc = mark_written(c, L, li, curs + b, m))) return rc;
         }
-        if ((rc = enqueue_pose(c, L, m, not_large_rotation))) return rc;
+        if ((rc = enqueue_pose(c, L, m, not_large_rotation, fuse))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
         if ((rc = end_call(c, L))) return rc;

@@ -111,7 +111,8 @@ void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
-                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero);
+                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
+                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr);   // x_fwd: also keep X
 // G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride);
@@ -124,7 +125,8 @@ void launch_B_zz_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const fl
 void launch_B_mul_inv_x(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
                         const float2* xsrc, size_t x_stride, const int* x_idx,
                         const float2* zsrc, size_t z_stride, const int* z_idx,
-                        float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero);
+                        float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
+                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr);   // x_fwd: also keep X
 // G from the cached Kzz spectrum / max of slot z_idx[item] and Kxz = fwd(buf plane 1)
 void launch_B_solve_cached(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                            size_t plane_stride, const unsigned* maxbuf, const float2* kzz, size_t kzz_stride,

@@ -694,7 +694,7 @@ struct BArgs {
     const float2* zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
     size_t in_plane_stride;                                       // SOLVE: plane 1 offset inside src item
     float2* dst; size_t dst_stride; const int* dst_slot;          // primary output
-    float2* dst2; size_t dst2_stride;                             // secondary output
+    float2* dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; float lambda;
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
@@ -794,6 +794,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             float2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
             if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+            if (a.dst2 && vst && j < DF::ML)                 // X is a result of its own (the frame's spectrum): keep it
+                store_strided(x[0], a.dst2 + (size_t)(a.dst2_slot ? a.dst2_slot[item] : item) * a.dst2_stride + loff, DF::ML);
 #pragma unroll
             for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(x[0][q], zv[q]);
             __syncthreads();
@@ -829,6 +831,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             float2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
             if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+            if (a.dst2 && vst && j < DF::ML)
+                store_strided(x[0], a.dst2 + (size_t)(a.dst2_slot ? a.dst2_slot[item] : item) * a.dst2_stride + loff, DF::ML);
 #pragma unroll
             for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(x[0][q], zv[q]);
             __syncthreads();
@@ -947,8 +951,10 @@ void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
-                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero) {
+                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
+                      float2* xstore, size_t xstore_stride, const int* xstore_slot) {
     BArgs a = base_bargs(g, t);
+    a.dst2 = x_fwd ? xstore : nullptr; a.dst2_stride = xstore_stride; a.dst2_slot = xstore_slot;
     a.maxbuf_zero = maxbuf_zero;
     a.src = xsrc; a.src_stride = x_stride; a.src_idx = x_idx; a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx;
     a.dst = out; a.dst_stride = item_stride; a.out_plane_stride = plane_stride;
@@ -971,10 +977,12 @@ void launch_B_zz_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const fl
 #undef CALL
 }
 void launch_B_mul_inv_x(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
-                        const float2* xsrc, size_t x_stride, const int* x_idx,
-                        const float2* zsrc, size_t z_stride, const int* z_idx,
-                        float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero) {
+                      const float2* xsrc, size_t x_stride, const int* x_idx,
+                      const float2* zsrc, size_t z_stride, const int* z_idx,
+                      float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
+                      float2* xstore, size_t xstore_stride, const int* xstore_slot) {
     BArgs a = base_bargs(g, t);
+    a.dst2 = x_fwd ? xstore : nullptr; a.dst2_stride = xstore_stride; a.dst2_slot = xstore_slot;
     a.src = xsrc; a.src_stride = x_stride; a.src_idx = x_idx; a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx;
     a.dst = out; a.dst_stride = item_stride; a.out_plane_stride = plane_stride; a.maxbuf_zero = maxbuf_zero;
     if (x_fwd) {
