@@ -92,6 +92,21 @@ int  nik_synchronize(nik_ctx* ctx);
  * Default off ($NIK_KZZ_CACHE=1 turns it on at creation); costs (H/2+1)*W + (PD/2+1)*PC complex per slot. */
 int  nik_set_kzz_cache(nik_ctx* ctx, int enable);
 
+/* ---- Camera undistortion: the step right before the path (MapBuilder::AddNewInput, map_builder.cc:31-33) ----
+ * nik_camera_maps     host only, no GPU: the map construction of Camera::Camera (camera.cc:46-47) --
+ *                     getOptimalNewCameraMatrix(K, D, size, alpha 0, size) and initUndistortRectifyMap(K, D, I,
+ *                     new_K, size, CV_16SC2): K = {fx, cx, fy, cy}, D = {k1, k2, p1, p2, k3};  outputs new_K (same
+ *                     order), map1[H*W*2] = integer source (x, y), map2[H*W] = fy*32 + fx (1/32 px fractions).
+ * nik_set_undistort   installs the maps (host pointers, copied; NULL, NULL removes them).  While installed, EVERY u8
+ *                     entry point (nik_intermedium_u8 / _batch_dev, nik_track_batch_dev, nik_tracker_push_*)
+ *                     takes the RAW camera frame: Camera::UndistortImage (camera.cc:92-93, cv::remap INTER_LINEAR,
+ *                     border 0) is fused into the u8 -> f32 conversion.  f32 entry points are unaffected.
+ * nik_undistort_dev   Camera::UndistortImage itself for n device images (u8 row-major -> u8), e.g. for a stitcher. */
+int  nik_camera_maps(const double K[4], const double D[5], int width, int height, double new_K[4],
+                     int16_t* map1, uint16_t* map2);
+int  nik_set_undistort(nik_ctx* ctx, const int16_t* map1, const uint16_t* map2);
+int  nik_undistort_dev(nik_ctx* ctx, int n, const uint8_t* d_raw, uint8_t* d_out);
+
 /* ---- ComputeIntermedium (correlation_flow.cc:89-95) ------------------------------------- */
 
 /* replaces MapBuilder::ComputeFFTResult (map_builder.cc:72-75): ConvertMatToNormalizedArray

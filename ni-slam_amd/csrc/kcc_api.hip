@@ -80,6 +80,7 @@ struct nik_ctx {
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
     // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
     bool kzz_cache = false;
+    int16_t* ud_map1 = nullptr; uint16_t* ud_map2 = nullptr;   // undistortion maps (nik_set_undistort); null = u8 inputs are already undistorted
     bool fuse_polar = true;       // tracking path: fuse the polar spectrum's last pass into the pose's first kernel ($NIK_FUSE_POLAR=0: off)
     float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
     std::vector<uint8_t> slot_kzz;       // 1: cache valid
@@ -402,6 +403,19 @@ std::string kname(const char* base, int len, const char* mode) {
 inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
 inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
 
+// u8 frames -> normalised f32 planes in the arena slots IX_DST (ConvertMatToNormalizedArray, utils.cc:110-118); with
+// undistortion maps installed the input is the RAW camera frame and Camera::UndistortImage (camera.cc:92-93) is
+// fused into the conversion.
+void enqueue_u8_to_plane(nik_ctx* c, Lane& L, int m, const uint8_t* d_u8) {
+    if (c->ud_map1) {
+        Stage st(c, L, "k_undistort_cvt", m * (1.0 * c->img.real_elems + Rb(c->img)) + 6.0 * c->img.real_elems);
+        launch_undistort_cvt(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->ud_map1, c->ud_map2, c->H, c->W);
+    } else {
+        Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
+        launch_cvt_u8(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->H, c->W);
+    }
+}
+
 // ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
 // arena slots listed in d_idx[IX_DST].
 // defer_polar_B: leave the polar spectrum's second (radius) pass to the caller -- the pose that follows fuses it into
@@ -631,6 +645,7 @@ void nik_destroy(nik_ctx* c) {
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
     (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
+    (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->rot_tab);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
@@ -662,6 +677,33 @@ int nik_set_kzz_cache(nik_ctx* c, int enable) {
     return NIK_OK;
 }
 
+int nik_set_undistort(nik_ctx* c, const int16_t* map1, const uint16_t* map2) {
+    if (!c || ((map1 == nullptr) != (map2 == nullptr))) return fail(c, NIK_ERR_INVALID_ARG, "both maps or neither");
+    int rc = drain_all(c);
+    if (rc) return rc;
+    for (Lane& L : c->lanes) HIP_TRY(c, hipStreamSynchronize(L.stream));
+    (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2); c->ud_map1 = nullptr; c->ud_map2 = nullptr;
+    if (!map1) return NIK_OK;
+    const size_t n = c->img.real_elems;
+    HIP_TRY(c, hipMalloc(&c->ud_map1, n * 2 * sizeof(int16_t)));
+    HIP_TRY(c, hipMalloc(&c->ud_map2, n * sizeof(uint16_t)));
+    HIP_TRY(c, hipMemcpy(c->ud_map1, map1, n * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(c->ud_map2, map2, n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    return NIK_OK;
+}
+
+int nik_undistort_dev(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_out) {
+    if (!c || !d_in || !d_out || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (!c->ud_map1) return fail(c, NIK_ERR_INVALID_ARG, "no undistortion maps installed (nik_set_undistort)");
+    if (n == 0) return NIK_OK;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    launch_undistort_u8(c->lanes[0].stream, n, d_in, d_out, c->ud_map1, c->ud_map2, c->H, c->W);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->lanes[0].stream));
+    return NIK_OK;
+}
+
 int nik_synchronize(nik_ctx* c) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc = drain_all(c);
@@ -684,8 +726,7 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
         if ((rc = begin_call(c, L))) return rc;
         for (int i = 0; i < m; ++i) { if ((rc = depend_for_write(c, L, li, dst[b + i]))) return rc; hidx(L, IX_DST)[i] = dst[b + i]; }
         if ((rc = upload_idx(c, L, IX_DST, m))) return rc;
-        { Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
-          launch_cvt_u8(L.stream, m, d_gray + (size_t)b * c->img.real_elems, didx(L, IX_DST), c->arena_img, c->H, c->W); }
+        enqueue_u8_to_plane(c, L, m, d_gray + (size_t)b * c->img.real_elems);
         enqueue_intermedium(c, L, m);
         HIP_TRY(c, hipGetLastError());
         if ((rc = mark_written(c, L, li, dst + b, m)) || (rc = end_call(c, L))) return rc;
@@ -829,8 +870,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
         if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
         bool fuse = false;
         if (d_gray) {
-            { Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
-              launch_cvt_u8(L.stream, m, d_gray + (size_t)b * c->img.real_elems, didx(L, IX_DST), c->arena_img, c->H, c->W); }
+            enqueue_u8_to_plane(c, L, m, d_gray + (size_t)b * c->img.real_elems);
             // the polar spectrum's last pass is fused into the pose's first kernel (not for the gaussian kernel,
             // which needs sum|X|^2 of the finished spectrum before that kernel runs)
             fuse = (c->cfg.kernel != 1) && c->fuse_polar;

@@ -62,6 +62,11 @@ PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for h
 // ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,
                    int H, int W);
+// Camera::UndistortImage (camera.cc:92-93): cv::remap with the fixed-point maps; u8 -> u8, and fused with the
+// u8 -> f32 column-major / 255 conversion (raw camera frame straight into the image arena)
+void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W);
+void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
+                          const int16_t* map1, const uint16_t* map2, int H, int W);
 
 // 8-bit RGB/BGR (interleaved) -> gray with OpenCV's integer luma weights
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr);

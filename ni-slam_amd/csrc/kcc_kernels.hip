@@ -184,6 +184,67 @@ void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst
 }
 
 // ------------------------------------------------------------------------------------------------
+// Camera::UndistortImage (camera.cc:92-93): cv::remap(8UC1, CV_16SC2 + CV_16UC1 maps, INTER_LINEAR, BORDER_CONSTANT 0)
+// ------------------------------------------------------------------------------------------------
+// remapBilinear<FixedPtCast<int, uchar, 15>>: 15-bit integer weights -- exact for 1/32 px fractions:
+// (32-fx)(32-fy)*32 ... , sum 32768 -- and out-of-image taps = border value 0.  Returns the u8 result.
+__device__ __forceinline__ int undistort_px(const uint8_t* __restrict__ in, int H, int W, int2 m1, int m2) {
+    const int sx = m1.x, sy = m1.y, fx = m2 & 31, fy = (m2 >> 5) & 31;
+    const bool x0 = (unsigned)sx < (unsigned)W, x1 = (unsigned)(sx + 1) < (unsigned)W;
+    const bool y0 = (unsigned)sy < (unsigned)H, y1 = (unsigned)(sy + 1) < (unsigned)H;
+    const uint8_t* p = in + (long)sy * W + sx;
+    const int t00 = (x0 && y0) ? p[0] : 0, t01 = (x1 && y0) ? p[1] : 0;
+    const int t10 = (x0 && y1) ? p[W] : 0, t11 = (x1 && y1) ? p[W + 1] : 0;
+    const int acc = ((32 - fx) * (32 - fy) * t00 + fx * (32 - fy) * t01 + (32 - fx) * fy * t10 + fx * fy * t11) * 32;
+    return (acc + (1 << 14)) >> 15;
+}
+// u8 -> u8 (the undistorted image itself, e.g. for the map stitcher)
+__global__ __launch_bounds__(256) void k_undistort_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                      const short2* __restrict__ map1, const uint16_t* __restrict__ map2, int H, int W) {
+    const int i = blockIdx.x * 256 + threadIdx.x, item = blockIdx.y;
+    if (i >= H * W) return;
+    const short2 m = map1[i];
+    dst[(size_t)item * H * W + i] = (uint8_t)undistort_px(src + (size_t)item * H * W, H, W, make_int2(m.x, m.y), map2[i]);
+}
+// raw u8 row-major -> undistorted f32 column-major / 255: k_cvt_u8 with the remap fused into its load
+__global__ __launch_bounds__(256) void k_undistort_cvt(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
+                                                       float* __restrict__ arena, const short2* __restrict__ map1,
+                                                       const uint16_t* __restrict__ map2, int H, int W) {
+    __shared__ float tile[64][65];                          // [x][y], odd pitch
+    const int item = blockIdx.z, tid = threadIdx.x;
+    const uint8_t* in = src + (size_t)item * H * W;
+    float* out = arena + (size_t)dst_slot[item] * H * W;
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int y = (tid >> 6) + 4 * it, x = tid & 63;    // one map row segment (64 entries) per wave: coalesced
+        const int r = r0 + y, c = c0 + x;
+        if (r < H && c < W) {
+            const short2 m = map1[(size_t)r * W + c];
+            tile[x][y] = (float)undistort_px(in, H, W, make_int2(m.x, m.y), map2[(size_t)r * W + c]) / 255.0f;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int x = (tid >> 4) + 16 * it, y = 4 * (tid & 15);
+        const int c = c0 + x, r = r0 + y;
+        if (c < W && r < H)
+            *reinterpret_cast<float4*>(out + (size_t)c * H + r) = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
+    }
+}
+void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W) {
+    hipLaunchKernelGGL(k_undistort_u8, dim3((H * W + 255) / 256, n), dim3(256), 0, s, d_in, d_out,
+                       reinterpret_cast<const short2*>(map1), map2, H, W);
+}
+void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
+                          const int16_t* map1, const uint16_t* map2, int H, int W) {
+    dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
+    hipLaunchKernelGGL(k_undistort_cvt, grid, block, 0, s, d_raw, d_dst_slot, arena_img,
+                       reinterpret_cast<const short2*>(map1), map2, H, W);
+}
+
+// ------------------------------------------------------------------------------------------------
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
 enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };

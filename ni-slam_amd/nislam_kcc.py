@@ -25,7 +25,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
-           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
+           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
 
 
 class NikConfig(C.Structure):
@@ -112,6 +112,9 @@ def load():
         L.nik_synchronize.argtypes = [P]
         L.nik_set_streams.argtypes = [P, I]
         L.nik_set_kzz_cache.argtypes = [P, I]
+        L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
+        L.nik_set_undistort.argtypes = [P, P, P]
+        L.nik_undistort_dev.argtypes = [P, I, P, P]
         L.nik_intermedium_u8.argtypes = [P, P, I, I]
         L.nik_intermedium_f32.argtypes = [P, P, I]
         L.nik_intermedium_batch_dev.argtypes = [P, I, P, P]
@@ -146,6 +149,17 @@ def _p(a):
 
 def _i32(seq):
     return np.ascontiguousarray(np.asarray(seq, dtype=np.int32))
+
+
+def camera_maps(K, D, W, H):
+    """Camera::Camera's map construction (camera.cc:46-47) on the host: K = (fx, cx, fy, cy), D = (k1, k2, p1, p2, k3)
+    -> new_K (4,), map1 int16 (H, W, 2), map2 uint16 (H, W).  Needs the library but no GPU."""
+    K = np.ascontiguousarray(K, np.float64); D = np.ascontiguousarray(D, np.float64)
+    newK = np.empty(4, np.float64); m1 = np.empty((H, W, 2), np.int16); m2 = np.empty((H, W), np.uint16)
+    rc = load().nik_camera_maps(_p(K), _p(D), int(W), int(H), _p(newK), _p(m1), _p(m2))
+    if rc:
+        raise NikError(rc, "nik_camera_maps: invalid intrinsics / size")
+    return newK, m1, m2
 
 
 class CorrelationFlow:
@@ -186,6 +200,19 @@ class CorrelationFlow:
 
     def set_streams(self, n):
         return self._L.nik_set_streams(self._ctx, int(n))
+
+    # ---- camera undistortion (Camera::Camera maps / Camera::UndistortImage, camera.cc:45-47,92-93) ----
+    def set_undistort(self, map1=None, map2=None):
+        """Install (or with None remove) the CV_16SC2 / CV_16UC1 maps: u8 entry points then take raw camera frames."""
+        if map1 is None:
+            self._chk(self._L.nik_set_undistort(self._ctx, None, None))
+            return
+        map1 = np.ascontiguousarray(map1, np.int16); map2 = np.ascontiguousarray(map2, np.uint16)
+        assert map1.shape == (self.H, self.W, 2) and map2.shape == (self.H, self.W)
+        self._chk(self._L.nik_set_undistort(self._ctx, _p(map1), _p(map2)))
+
+    def undistort_dev(self, d_raw_ptr, n, d_out_ptr):
+        self._chk(self._L.nik_undistort_dev(self._ctx, int(n), C.c_void_p(int(d_raw_ptr)), C.c_void_p(int(d_out_ptr))))
 
     # ---- ComputeIntermedium ------------------------------------------------------------------
     def intermedium_u8(self, gray, dst):

@@ -11,6 +11,7 @@
 
 #include <malloc.h>
 #include <math.h>
+#include <float.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -652,4 +653,103 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
     /* wall time of the timed units = total wall minus the (thread-averaged) key preparation */
     if (seconds_unit) *seconds_unit = t_total - t_key / nthreads;
     return rc;
+}
+
+/* ======================================================================================================
+ * Camera undistortion (camera.cc:45-47, 92-93)
+ * ====================================================================================================== */
+
+/* cvUndistortPoints (C API default criteria: 5 fixed-point iterations), no R / P: pixel -> normalised coords */
+static void undistort_point(double u, double v, const double K[4], const double D[5], double* xo, double* yo) {
+    const double fx = K[0], cx = K[1], fy = K[2], cy = K[3];
+    const double ifx = 1. / fx, ify = 1. / fy;
+    const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; ++j) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0 * r2 + 0) * r2 + 0) * r2) / (1 + ((k3 * r2 + k2) * r2 + k1) * r2);
+        if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+        const double deltaX = 2 * p1 * x * y + p2 * (r2 + 2 * x * x);
+        const double deltaY = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    *xo = x; *yo = y;
+}
+
+/* cvGetOptimalNewCameraMatrix(alpha = 0, newImgSize = imgSize, centerPrincipalPoint = false): the inscribed
+ * rectangle of a 9x9 grid of undistorted points (icvGetRectangles; points are stored as float) mapped to the viewport */
+void ora_optimal_new_camera_matrix(const double K[4], const double D[5], int width, int height, double newK[4]) {
+    const int N = 9;
+    float iX0 = -FLT_MAX, iX1 = FLT_MAX, iY0 = -FLT_MAX, iY1 = FLT_MAX;
+    for (int y = 0; y < N; ++y)
+        for (int x = 0; x < N; ++x) {
+            const float px = (float)x * width / (N - 1), py = (float)y * height / (N - 1);
+            double ux, uy;
+            undistort_point((double)px, (double)py, K, D, &ux, &uy);
+            const float qx = (float)ux, qy = (float)uy;
+            if (x == 0)     iX0 = iX0 > qx ? iX0 : qx;
+            if (x == N - 1) iX1 = iX1 < qx ? iX1 : qx;
+            if (y == 0)     iY0 = iY0 > qy ? iY0 : qy;
+            if (y == N - 1) iY1 = iY1 < qy ? iY1 : qy;
+        }
+    const float inner_x = iX0, inner_y = iY0, inner_w = iX1 - iX0, inner_h = iY1 - iY0;   /* cv::Rect_<float> */
+    const double fx0 = (width - 1) / inner_w, fy0 = (height - 1) / inner_h;
+    newK[0] = fx0; newK[1] = -fx0 * inner_x; newK[2] = fy0; newK[3] = -fy0 * inner_y;
+}
+
+static inline int sat_int_d(double v) {      /* saturate_cast<int>(double) = cvRound with saturation */
+    if (v >= 2147483647.0) return 2147483647;
+    if (v <= -2147483648.0) return (-2147483647 - 1);
+    return cv_round_d(v);
+}
+
+/* cv::initUndistortRectifyMap(K, D, R = I, newK, size, CV_16SC2): per destination pixel the distorted source
+ * position in 1/32 px fixed point */
+void ora_undistort_maps(const double K[4], const double D[5], const double newK[4], int width, int height,
+                        int16_t* map1, uint16_t* map2) {
+    const double fx = K[0], u0 = K[1], fy = K[2], v0 = K[3];
+    const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+    /* iR = (newK * I)^-1 for the upper-triangular [[fx',0,cx'],[0,fy',cy'],[0,0,1]] */
+    const double ir[9] = { 1. / newK[0], 0, -newK[1] / newK[0],  0, 1. / newK[2], -newK[3] / newK[2],  0, 0, 1 };
+    for (int i = 0; i < height; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < width; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double w = 1. / _w, x = _x * w, y = _y * w;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2));
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy);
+            const double u = fx * xd + u0, v = fy * yd + v0;
+            const int iu = sat_int_d(u * INTER_TAB_SIZE), iv = sat_int_d(v * INTER_TAB_SIZE);
+            map1[((size_t)i * width + j) * 2 + 0] = (int16_t)(iu >> INTER_BITS);
+            map1[((size_t)i * width + j) * 2 + 1] = (int16_t)(iv >> INTER_BITS);
+            map2[(size_t)i * width + j] = (uint16_t)((iv & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (iu & (INTER_TAB_SIZE - 1)));
+        }
+    }
+}
+
+/* cv::remap(8UC1, CV_16SC2 + CV_16UC1 maps, INTER_LINEAR, BORDER_CONSTANT 0): fixed-point bilinear with the
+ * 15-bit integer weight table (INTER_REMAP_COEF_BITS); for 1/32 px fractions the weights are exact multiples of 32
+ * and sum to 32768, so they are computed directly.  Out-of-image taps contribute the border value 0. */
+void ora_remap_u8(const uint8_t* src, int width, int height, const int16_t* map1, const uint16_t* map2, uint8_t* dst) {
+    for (int i = 0; i < height; ++i)
+        for (int j = 0; j < width; ++j) {
+            const int sx = map1[((size_t)i * width + j) * 2], sy = map1[((size_t)i * width + j) * 2 + 1];
+            const int m = map2[(size_t)i * width + j] & (INTER_TAB_SIZE * INTER_TAB_SIZE - 1);
+            const int fx = m & (INTER_TAB_SIZE - 1), fy = m >> INTER_BITS;
+            const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+            int acc = 0;
+            if (sy >= 0 && sy < height) {
+                if (sx >= 0 && sx < width)         acc += w00 * src[(size_t)sy * width + sx];
+                if (sx + 1 >= 0 && sx + 1 < width) acc += w01 * src[(size_t)sy * width + sx + 1];
+            }
+            if (sy + 1 >= 0 && sy + 1 < height) {
+                if (sx >= 0 && sx < width)         acc += w10 * src[(size_t)(sy + 1) * width + sx];
+                if (sx + 1 >= 0 && sx + 1 < width) acc += w11 * src[(size_t)(sy + 1) * width + sx + 1];
+            }
+            dst[(size_t)i * width + j] = (uint8_t)((acc + (1 << 14)) >> 15);   /* FixedPtCast<int, uchar, 15> */
+        }
 }

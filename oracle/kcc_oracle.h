@@ -122,6 +122,18 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n,
                     double* poses /*n x 3*/, double* infos /*n x 3*/,
                     ora_pose_debug* dbgs /*n or NULL*/, double* seconds_unit);
 
+
+/* ---- camera undistortion: the step right before the path ----------------------------------------------
+ * /root/reference/src/camera.cc:45-47 (getOptimalNewCameraMatrix(alpha=0) + initUndistortRectifyMap(CV_16SC2))
+ * and :92-93 (cv::remap(INTER_LINEAR), u8, BORDER_CONSTANT 0).  OpenCV 4.2 semantics restated from the
+ * published algorithm [recalled, could not be validated against a real OpenCV here].
+ * K = {fx, cx, fy, cy}; D = {k1, k2, p1, p2, k3}. */
+void ora_optimal_new_camera_matrix(const double K[4], const double D[5], int width, int height, double newK[4]);
+void ora_undistort_maps(const double K[4], const double D[5], const double newK[4], int width, int height,
+                        int16_t* map1 /* H*W*2: (sx, sy) */, uint16_t* map2 /* H*W: fy*32 + fx */);
+void ora_remap_u8(const uint8_t* src_rowmajor, int width, int height, const int16_t* map1, const uint16_t* map2,
+                  uint8_t* dst_rowmajor);
+
 #ifdef __cplusplus
 }
 #endif

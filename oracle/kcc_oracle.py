@@ -78,6 +78,9 @@ def lib():
         L.ora_compute_pose.argtypes = [P, P, P, P, P, C.c_int, C.c_int, P, P, P]
         L.ora_track_pairs.argtypes = [C.POINTER(OraConfig), C.c_int, C.c_int, C.c_int, P, P,
                                       C.c_int, C.c_int, C.c_int, P, P, P, P]
+        L.ora_optimal_new_camera_matrix.argtypes = [P, P, C.c_int, C.c_int, P]
+        L.ora_undistort_maps.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
+        L.ora_remap_u8.argtypes = [P, C.c_int, C.c_int, P, P, P]
         _lib = L
     return _lib
 
@@ -212,3 +215,30 @@ def track_pairs(cfg, key_imgs, cur_imgs, not_large_rotation=True, faithful=False
     if rc:
         raise ValueError("oracle track_pairs failed rc=%d" % rc)
     return poses, infos, [d.as_dict() for d in dbgs], secs.value
+
+
+# ---- camera undistortion (camera.cc:45-47, 92-93) -------------------------------------------------------
+def optimal_new_camera_matrix(K, D, W, H):
+    """getOptimalNewCameraMatrix(K, D, (W,H), alpha=0, (W,H)); K = (fx, cx, fy, cy), D = (k1, k2, p1, p2, k3)."""
+    K = np.ascontiguousarray(K, np.float64); D = np.ascontiguousarray(D, np.float64)
+    out = np.empty(4, np.float64)
+    lib().ora_optimal_new_camera_matrix(_p(K), _p(D), W, H, _p(out))
+    return out
+
+
+def undistort_maps(K, D, newK, W, H):
+    """initUndistortRectifyMap(K, D, I, newK, (W,H), CV_16SC2) -> map1 int16 (H,W,2), map2 uint16 (H,W)."""
+    K = np.ascontiguousarray(K, np.float64); D = np.ascontiguousarray(D, np.float64)
+    newK = np.ascontiguousarray(newK, np.float64)
+    m1 = np.empty((H, W, 2), np.int16); m2 = np.empty((H, W), np.uint16)
+    lib().ora_undistort_maps(_p(K), _p(D), _p(newK), W, H, _p(m1), _p(m2))
+    return m1, m2
+
+
+def remap_u8(img, map1, map2):
+    """cv::remap(img, map1, map2, INTER_LINEAR) for a u8 row-major image (Camera::UndistortImage)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.empty((H, W), np.uint8)
+    lib().ora_remap_u8(_p(img), W, H, _p(np.ascontiguousarray(map1, np.int16)), _p(np.ascontiguousarray(map2, np.uint16)), _p(out))
+    return out

@@ -197,3 +197,67 @@ class CorrelationFlowNp:
         pose = np.array([trans[1], trans[0], float(theta)], np.float64)
         info = np.array([psr_t, psr_t, psr_r], np.float64)
         return pose, info, dbg
+
+
+# ---- camera undistortion (camera.cc:45-47, 92-93), vectorised restatement ------------------------------
+def _undistort_points(u, v, K, D, iters=5):
+    fx, cx, fy, cy = K
+    k1, k2, p1, p2, k3 = D
+    x = (u - cx) * (1.0 / fx); y = (v - cy) * (1.0 / fy)
+    x0, y0 = x.copy(), y.copy()
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icdist = 1.0 / (1 + ((k3 * r2 + k2) * r2 + k1) * r2)
+        dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+        dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+        x = (x0 - dx) * icdist; y = (y0 - dy) * icdist
+    return x, y
+
+
+def optimal_new_camera_matrix(K, D, W, H):
+    N = 9
+    gx = (np.arange(N, dtype=np.float32) * np.float32(W) / np.float32(N - 1)).astype(np.float32)
+    gy = (np.arange(N, dtype=np.float32) * np.float32(H) / np.float32(N - 1)).astype(np.float32)
+    px, py = np.meshgrid(gx, gy)                      # [y, x]
+    ux, uy = _undistort_points(px.astype(np.float64), py.astype(np.float64), K, D)
+    ux = ux.astype(np.float32); uy = uy.astype(np.float32)
+    iX0 = ux[:, 0].max(); iX1 = ux[:, N - 1].min(); iY0 = uy[0, :].max(); iY1 = uy[N - 1, :].min()
+    # (int) / (float) is a float division in the reference's C++ (cv::Rect_<float>), widened to double afterwards
+    fx0 = float(np.float32(W - 1) / np.float32(iX1 - iX0)); fy0 = float(np.float32(H - 1) / np.float32(iY1 - iY0))
+    return np.array([fx0, -fx0 * float(iX0), fy0, -fy0 * float(iY0)])
+
+
+def undistort_maps(K, D, newK, W, H):
+    fx, u0, fy, v0 = K
+    k1, k2, p1, p2, k3 = D
+    ir0, ir2 = 1.0 / newK[0], -newK[1] / newK[0]
+    ir4, ir5 = 1.0 / newK[2], -newK[3] / newK[2]
+    # running sums along a row (the reference accumulates _x += ir[0] per column)
+    xs = np.empty(W); acc = ir2
+    for j in range(W):
+        xs[j] = acc; acc += ir0
+    ys = np.arange(H) * ir4 + ir5
+    x = np.broadcast_to(xs[None, :], (H, W)); y = np.broadcast_to(ys[:, None], (H, W))
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2; _2xy = 2 * x * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2)
+    yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy
+    iu = np.rint(( fx * xd + u0) * INTER_TAB).astype(np.int64)
+    iv = np.rint(( fy * yd + v0) * INTER_TAB).astype(np.int64)
+    m1 = np.stack([iu >> INTER_BITS, iv >> INTER_BITS], axis=-1).astype(np.int16)
+    m2 = ((iv & (INTER_TAB - 1)) * INTER_TAB + (iu & (INTER_TAB - 1))).astype(np.uint16)
+    return m1, m2
+
+
+def remap_u8(img, map1, map2):
+    img = np.asarray(img, np.uint8); H, W = img.shape
+    sx = map1[..., 0].astype(np.int64); sy = map1[..., 1].astype(np.int64)
+    fx = (map2 & 31).astype(np.int64); fy = (map2 >> 5).astype(np.int64) & 31
+    pad = np.zeros((H + 2, W + 2), np.int64); pad[1:-1, 1:-1] = img       # border value 0 one pixel around
+    def tap(xx, yy):
+        ok = (xx >= -1) & (xx <= W) & (yy >= -1) & (yy <= H)
+        return np.where(ok, pad[np.clip(yy, -1, H) + 1, np.clip(xx, -1, W) + 1], 0)
+    acc = ((32 - fx) * (32 - fy) * 32 * tap(sx, sy) + fx * (32 - fy) * 32 * tap(sx + 1, sy)
+           + (32 - fx) * fy * 32 * tap(sx, sy + 1) + fx * fy * 32 * tap(sx + 1, sy + 1))
+    return ((acc + (1 << 14)) >> 15).astype(np.uint8)
