@@ -189,6 +189,7 @@ typedef struct {
     double  response[3];           /* ComputePose's return value                                              */
     double  cf_pose[3];            /* _current_cf_pose (image plane, pixels)                                  */
     double  robot_pose[3];         /* _current_pose                                                           */
+    double  distance;              /* _distance: accumulated travel of the keyframes so far (SetFrameDistance) */
 } nik_track_output;
 
 /* replaces MapBuilder::MapBuilder's tracking members (map_builder.cc:18-28); the tracker borrows ctx */
@@ -203,6 +204,43 @@ int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_trac
 int  nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out);
 /* number of keyframes inserted so far and their slots (for loop closure: nik_match over these) */
 int  nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n);
+
+/* ---- keyframe map + loop-closure candidate management (src/map.cc, src/loop_closure.cc) ------------------
+ * Decides WHICH keyframes a new keyframe is registered against; the registrations are one nik_match call.
+ * Candidates are visited in ascending frame id (the reference's grid overload iterates unordered_sets, i.e. in
+ * unspecified order; with its strict '>' the order only breaks exact ties -- here the lowest id wins). */
+typedef struct {
+    double  grid_scale;              /* MapConfig::grid_scale (read_configs.h:34-36), > 0                       */
+    int32_t to_find_loop;            /* LoopClosureConfig (read_configs.h:38-44); informational here            */
+    int32_t frame_gap_thr;           /* > 0: skip candidates closer than this many frame ids                    */
+    double  distance_thr;            /* > 0: skip candidates whose accumulated travel differs by less than this */
+    double  position_response_thr, angle_response_thr;   /* found = PSR_t > position_thr && PSR_r > angle_thr   */
+} nik_loop_config;
+
+typedef struct {
+    int32_t  found;                  /* LoopClosureResult::found                                                */
+    int32_t  cur_frame_id, loop_frame_id;   /* loop_frame_id = -1: no candidate                                 */
+    nik_frame loop_slot;
+    int32_t  n_candidates;           /* candidates that passed the filters (= ComputePose calls of the reference) */
+    double   response[3];            /* best candidate's ComputePose return value; (-1,-1,-1) if none           */
+    double   relative_pose[3];       /* its pose (image-centre based: apply ConvertCenterToPrincipal as MapBuilder::FindLoopClosure does) */
+} nik_loop_result;
+
+typedef struct nik_map nik_map;
+/* replaces Map::Map + LoopClosure::LoopClosure.  ctx may be NULL for candidate queries only (no GPU needed). */
+int  nik_map_create(nik_ctx* ctx, const nik_loop_config* cfg, nik_map** out);
+void nik_map_destroy(nik_map* m);
+/* Map::AddFrame (map.cc:17-30; the first frame's id is forced to 0) + Map::SetFrameDistance (:32-34; distance may be
+ * NULL = never set, GetFrameDistance then reports -1).  `slot` is the device slot holding the keyframe's spectra. */
+int  nik_map_add_frame(nik_map* m, int frame_id, nik_frame slot, const double pose[3], const double* distance);
+int  nik_map_size(const nik_map* m);
+/* the frames LoopClosure::FindLoopClosure would call ComputePose on for keyframe cur_frame_id (already added):
+ * all frames (prior_pose NULL, loop_closure.cc:10-15) or those in the 3 x 3 grid cells around prior_pose
+ * (:17-33), minus the frame-gap and travel-distance filters (:43-53). */
+int  nik_map_candidates(const nik_map* m, int cur_frame_id, const double* prior_pose, int* frame_ids, int cap, int* n);
+/* LoopClosure::FindLoopClosure (loop_closure.cc:36-73): every candidate against the current keyframe
+ * (not_large_rotation = false) in one batched nik_match; the largest response.sum() wins. */
+int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, nik_loop_result* out);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

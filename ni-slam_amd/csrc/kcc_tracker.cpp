@@ -81,7 +81,7 @@ void first_frame(nik_tracker* t, nik_frame slot, nik_track_output& o) {
     memset(&o, 0, sizeof(o));
     o.frame_id = t->frame_id++; o.inserted = 1; o.good_tracking = 0; o.key_frame_id = -1; o.slot = slot;
     for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cf[k]; o.robot_pose[k] = robot[k]; }
-    t->distance = 0; t->init = true;
+    t->distance = 0; t->init = true; o.distance = 0;
     t->last_cf_pose = cf; t->last_cf_real_pose = real; t->last_pose = robot;         // UpdateIntermedium (:99-106)
     t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot);
 }
@@ -115,7 +115,7 @@ bool apply_result(nik_tracker* t, const nik_pose_result& r, nik_frame slot, nik_
         if (insert) t->distance += dist;
     }
     for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cur_cf[k]; o.robot_pose[k] = cur_pose[k]; }
-    o.inserted = insert;
+    o.inserted = insert; o.distance = t->distance;
     if (insert) {
         // UpdateIntermedium() (:99-106): this frame is the new keyframe
         t->last_cf_pose = cur_cf; t->last_cf_real_pose = cur_real; t->last_pose = cur_pose;

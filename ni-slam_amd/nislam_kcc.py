@@ -25,7 +25,8 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
-           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes"]
+           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
+           "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
 
 
 class NikConfig(C.Structure):
@@ -58,12 +59,28 @@ class NikTrackerConfig(C.Structure):
 
 class NikTrackOutput(C.Structure):
     _fields_ = [("frame_id", C.c_int32), ("inserted", C.c_int32), ("good_tracking", C.c_int32), ("key_frame_id", C.c_int32),
-                ("slot", C.c_int32), ("response", C.c_double * 3), ("cf_pose", C.c_double * 3), ("robot_pose", C.c_double * 3)]
+                ("slot", C.c_int32), ("response", C.c_double * 3), ("cf_pose", C.c_double * 3), ("robot_pose", C.c_double * 3),
+                ("distance", C.c_double)]
 
     def as_dict(self):
         return dict(frame_id=self.frame_id, inserted=bool(self.inserted), good_tracking=bool(self.good_tracking),
                     key_frame_id=self.key_frame_id, slot=self.slot, response=list(self.response), cf_pose=list(self.cf_pose),
-                    robot_pose=list(self.robot_pose))
+                    robot_pose=list(self.robot_pose), distance=self.distance)
+
+
+class NikLoopConfig(C.Structure):
+    """mirrors nik_loop_config (MapConfig + LoopClosureConfig, read_configs.h:34-44)"""
+    _fields_ = [("grid_scale", C.c_double), ("to_find_loop", C.c_int32), ("frame_gap_thr", C.c_int32), ("distance_thr", C.c_double),
+                ("position_response_thr", C.c_double), ("angle_response_thr", C.c_double)]
+
+
+class NikLoopResult(C.Structure):
+    _fields_ = [("found", C.c_int32), ("cur_frame_id", C.c_int32), ("loop_frame_id", C.c_int32), ("loop_slot", C.c_int32),
+                ("n_candidates", C.c_int32), ("response", C.c_double * 3), ("relative_pose", C.c_double * 3)]
+
+    def as_dict(self):
+        return dict(found=bool(self.found), cur_frame_id=self.cur_frame_id, loop_frame_id=self.loop_frame_id, loop_slot=self.loop_slot,
+                    n_candidates=self.n_candidates, response=list(self.response), relative_pose=list(self.relative_pose))
 
 
 class NikStageStat(C.Structure):
@@ -113,6 +130,13 @@ def load():
         L.nik_set_streams.argtypes = [P, I]
         L.nik_set_kzz_cache.argtypes = [P, I]
         L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
+        L.nik_map_create.argtypes = [P, P, P]
+        L.nik_map_destroy.argtypes = [P]
+        L.nik_map_destroy.restype = None
+        L.nik_map_add_frame.argtypes = [P, I, I, P, P]
+        L.nik_map_size.argtypes = [P]
+        L.nik_map_candidates.argtypes = [P, I, P, P, I, P]
+        L.nik_map_find_loop.argtypes = [P, I, P, P]
         L.nik_set_undistort.argtypes = [P, P, P]
         L.nik_undistort_dev.argtypes = [P, I, P, P]
         L.nik_intermedium_u8.argtypes = [P, P, I, I]
@@ -388,3 +412,54 @@ class Tracker:
         n = C.c_int(0)
         self._L.nik_tracker_keyframes(self._t, _p(slots), len(slots), C.addressof(n))
         return slots[: n.value].tolist()
+
+
+def loop_config(grid_scale=0.1, to_find_loop=True, frame_gap_thr=100, distance_thr=5.0, position_response_thr=60.0,
+                angle_response_thr=60.0):
+    """defaults: /root/reference/configs/config_ntu.yaml:24-33"""
+    return NikLoopConfig(grid_scale, int(to_find_loop), int(frame_gap_thr), distance_thr, position_response_thr, angle_response_thr)
+
+
+class KeyframeMap:
+    """Map + LoopClosure candidate management (map.cc, loop_closure.cc).  flow=None: candidate queries only (no GPU)."""
+
+    def __init__(self, flow, cfg):
+        self._flow, self._L = flow, load()
+        self._m = C.c_void_p()
+        rc = self._L.nik_map_create(flow._ctx if flow is not None else None, C.byref(cfg), C.byref(self._m))
+        if rc:
+            raise NikError(rc, "nik_map_create failed")
+
+    def close(self):
+        if getattr(self, "_m", None):
+            self._L.nik_map_destroy(self._m)
+            self._m = None
+
+    __del__ = close
+
+    def __len__(self):
+        return self._L.nik_map_size(self._m)
+
+    def add_frame(self, frame_id, slot, pose, distance=None):
+        pose = np.ascontiguousarray(pose, np.float64)
+        d = None if distance is None else np.array([distance], np.float64)
+        rc = self._L.nik_map_add_frame(self._m, int(frame_id), int(slot), _p(pose), _p(d))
+        if rc:
+            raise NikError(rc, "nik_map_add_frame: duplicate frame id / bad argument")
+
+    def candidates(self, cur_frame_id, prior_pose=None):
+        ids = np.zeros(max(len(self), 1), np.int32)
+        n = C.c_int(0)
+        pp = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float64)
+        rc = self._L.nik_map_candidates(self._m, int(cur_frame_id), _p(pp), _p(ids), len(ids), C.addressof(n))
+        if rc:
+            raise NikError(rc, "nik_map_candidates: unknown frame id")
+        return ids[: n.value].tolist()
+
+    def find_loop(self, cur_frame_id, prior_pose=None):
+        out = NikLoopResult()
+        pp = None if prior_pose is None else np.ascontiguousarray(prior_pose, np.float64)
+        rc = self._L.nik_map_find_loop(self._m, int(cur_frame_id), _p(pp), C.addressof(out))
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode() if self._flow is not None else "no context")
+        return out.as_dict()
