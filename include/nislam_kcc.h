@@ -242,6 +242,13 @@ int  nik_map_candidates(const nik_map* m, int cur_frame_id, const double* prior_
  * (not_large_rotation = false) in one batched nik_match; the largest response.sum() wins. */
 int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, nik_loop_result* out);
 
+/* MapBuilder's map side for the tracker (map_builder.cc:61-65,168-178): with a map attached (before the first frame;
+ * borrowed), every keyframe is added to it with its robot pose and accumulated distance, and -- if to_find_loop --
+ * searched for a loop closure around that pose; found loops accumulate like MapBuilder::_loop_matches
+ * (relative_pose already passed through ConvertCenterToPrincipal).  Pose-graph optimisation is out of scope. */
+int  nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop);
+int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on nik_stream() around every hot-path launch.

@@ -48,6 +48,25 @@ struct nik_tracker {
     V3 last_cf_pose{}, last_cf_real_pose{}, last_pose{};
     std::vector<nik_frame> free_slots;
     std::vector<nik_frame> keyframes;
+    nik_map* map = nullptr;                  // optional (borrowed): keyframes are added to it and searched for loops
+    int to_find_loop = 0;
+    std::vector<nik_loop_result> loops;      // MapBuilder::_loop_matches (never cleared here: no optimiser consumes them)
+    int map_rc = NIK_OK;                     // first error of a map / loop-closure call inside a push
+
+    // the map side of AddNewInput for a frame that became a keyframe (map_builder.cc:61-65,168-178)
+    void keyframe_to_map(const nik_track_output& o, bool search) {
+        if (!map || map_rc) return;
+        if ((map_rc = nik_map_add_frame(map, o.frame_id, o.slot, o.robot_pose, &o.distance))) return;
+        if (!search || !to_find_loop) return;
+        nik_loop_result lr;
+        if ((map_rc = nik_map_find_loop(map, o.frame_id, o.robot_pose, &lr))) return;     // prior = _current_pose (:169)
+        if (lr.found) {
+            V3 rp; for (int k = 0; k < 3; ++k) rp[k] = lr.relative_pose[k];
+            rp = center_to_principal(rp);                                                  // :171
+            for (int k = 0; k < 3; ++k) lr.relative_pose[k] = rp[k];
+            loops.push_back(lr);
+        }
+    }
 
     // Camera::ConvertCenterToPrincipal (src/camera.cc:148-158)
     V3 center_to_principal(const V3& c) const {
@@ -84,6 +103,7 @@ void first_frame(nik_tracker* t, nik_frame slot, nik_track_output& o) {
     t->distance = 0; t->init = true; o.distance = 0;
     t->last_cf_pose = cf; t->last_cf_real_pose = real; t->last_pose = robot;         // UpdateIntermedium (:99-106)
     t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot);
+    t->keyframe_to_map(o, false);                                                       // Initialize(): AddFrame + distance 0, no search
 }
 
 // everything AddNewInput does with one ComputePose result (map_builder.cc:42-68); returns whether it was inserted
@@ -120,6 +140,7 @@ bool apply_result(nik_tracker* t, const nik_pose_result& r, nik_frame slot, nik_
         // UpdateIntermedium() (:99-106): this frame is the new keyframe
         t->last_cf_pose = cur_cf; t->last_cf_real_pose = cur_real; t->last_pose = cur_pose;
         t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot); o.slot = slot;
+        t->keyframe_to_map(o, true);
     }
     return insert;
 }
@@ -142,6 +163,20 @@ int nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker*
 }
 
 void nik_tracker_destroy(nik_tracker* t) { delete t; }
+
+int nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop) {
+    if (!t) return NIK_ERR_INVALID_ARG;
+    if (t->init && m) return NIK_ERR_INVALID_ARG;         // the map must see every keyframe: attach before the first frame
+    t->map = m; t->to_find_loop = to_find_loop;
+    return NIK_OK;
+}
+
+int nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n) {
+    if (!t || !n) return NIK_ERR_INVALID_ARG;
+    *n = (int)t->loops.size();
+    for (int i = 0; i < *n && i < cap && out; ++i) out[i] = t->loops[i];
+    return NIK_OK;
+}
 
 int nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n) {
     if (!t || !n) return NIK_ERR_INVALID_ARG;
@@ -188,7 +223,7 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     }
     // recycle the slots of frames that did not become keyframes
     for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]);
-    return NIK_OK;
+    return t->map_rc;
 }
 
 int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out) {
@@ -199,11 +234,11 @@ int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_tra
     int rc = nik_intermedium_u8(t->ctx, gray, stride, s);
     if (rc) return rc;
     t->free_slots.pop_back();
-    if (!t->init) { first_frame(t, s, *out); return NIK_OK; }
+    if (!t->init) { first_frame(t, s, *out); return t->map_rc; }
     nik_pose_result r;
     if ((rc = nik_pose(t->ctx, t->key_slot, s, 1, nullptr, nullptr, &r))) { t->free_slots.push_back(s); return rc; }
     if (!apply_result(t, r, s, *out)) t->free_slots.push_back(s);
-    return NIK_OK;
+    return t->map_rc;
 }
 
 }  // extern "C"

@@ -26,7 +26,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
 
 
 class NikConfig(C.Structure):
@@ -130,6 +130,8 @@ def load():
         L.nik_set_streams.argtypes = [P, I]
         L.nik_set_kzz_cache.argtypes = [P, I]
         L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
+        L.nik_tracker_attach_map.argtypes = [P, P, I]
+        L.nik_tracker_loops.argtypes = [P, P, I, P]
         L.nik_map_create.argtypes = [P, P, P]
         L.nik_map_destroy.argtypes = [P]
         L.nik_map_destroy.restype = None
@@ -406,6 +408,19 @@ class Tracker:
         if rc:
             raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
         return out.as_dict()
+
+    def attach_map(self, kmap, to_find_loop=True):
+        rc = self._L.nik_tracker_attach_map(self._t, kmap._m if kmap is not None else None, int(bool(to_find_loop)))
+        if rc:
+            raise NikError(rc, "nik_tracker_attach_map: attach before the first frame")
+        self._map = kmap                                   # keep it alive
+
+    def loops(self):
+        n = C.c_int(0)
+        self._L.nik_tracker_loops(self._t, None, 0, C.addressof(n))
+        out = (NikLoopResult * max(n.value, 1))()
+        self._L.nik_tracker_loops(self._t, C.cast(out, C.c_void_p), n.value, C.addressof(n))
+        return [out[i].as_dict() for i in range(n.value)]
 
     def keyframes(self):
         slots = np.zeros(self._flow.max_frames, np.int32)

@@ -77,3 +77,68 @@ def test_tracker_matches_reference_logic(geom, n, window):
         for k in ("frame_id", "inserted", "good_tracking", "key_frame_id", "response", "cf_pose", "robot_pose"):
             assert o[k] == g[k], k
     trk.close(); trk2.close(); flow.close(); flow2.close()
+
+
+@pytest.mark.gpu
+def test_tracker_with_map_finds_loops():
+    """MapBuilder::AddNewInput's map side (map_builder.cc:61-65,168-178): keyframes go into the map with pose and
+    travelled distance and are searched for loops; an out-and-back trajectory must close on its early keyframes,
+    with exactly the matches the restated reference logic (RefTracker + RefMap over the oracle) finds."""
+    import torch
+    from ref_map import RefMap
+    N = nik()
+    geom = SMALL; H, W = geom["H"], geom["W"]
+    cv = synth.canvas(31, H, W)
+    path = [(2 * i, 3 * i) for i in range(10)] + [(2 * i, 3 * i + 1) for i in range(8, -1, -1)]      # out, then back beside it
+    frames = np.stack([synth.window(cv, H, W, dy, dx) for dy, dx in path])
+    n = len(frames)
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    flow = N.CorrelationFlow(cfg, H, W, max_batch=6, max_frames=n + 8)
+    tc = N.tracker_config(fx=600.0 * W / 640, fy=600.0 * W / 640, cx=W / 2 - 1.5, cy=H / 2 + 0.75, height=0.1,
+                          max_distance=0.002, max_angle=0.02, lower_response_thr=8.0, upper_response_thr=9.0)
+    lkw = dict(grid_scale=0.01, frame_gap_thr=4, distance_thr=0.004, position_response_thr=12.0, angle_response_thr=12.0)
+    trk = N.Tracker(flow, tc)
+    kmap = N.KeyframeMap(flow, N.loop_config(**lkw))
+    trk.attach_map(kmap, True)
+    d = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+    got = []
+    for b in range(0, n, 6):
+        m = min(6, n - b)
+        got += trk.push_dev(d[b:b + m].data_ptr(), m)
+    loops = trk.loops()
+    # ---- the same with the restated reference logic over the oracle
+    ocfg = ko.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    ora = ko.Oracle(ocfg, H, W)
+    ref = RefTracker(ora, H, W, fx=tc.fx, fy=tc.fy, cx=tc.cx, cy=tc.cy, height=tc.height,
+                     max_distance=tc.max_distance, max_angle=tc.max_angle, lower=8.0, upper=9.0)
+    rmap = RefMap(**lkw)
+    spectra, want_loops = {}, []
+    for i, f in enumerate(frames):
+        w = ref.add_new_input(f)
+        assert (got[i]["inserted"], got[i]["key_frame_id"]) == (w["inserted"], w["key_frame_id"]), i
+        if not w["inserted"]:
+            continue
+        assert got[i]["distance"] == pytest.approx(ref.distance, abs=1e-12)
+        f32 = ora.normalize_u8(f); spectra[i] = (f32,) + tuple(ora.intermedium(f32))
+        rmap.add_frame(i, w["robot_pose"], ref.distance)
+        if i == 0:
+            continue
+
+        def cp(fid, i=i):
+            pose, info, _ = ora.compute_pose(spectra[fid][1], spectra[i][0], spectra[fid][2], spectra[i][2], False)
+            return pose, info
+        r = rmap.find_loop(i, cp, w["robot_pose"])
+        if r["found"]:
+            r["relative_pose"] = list(ref.center_to_principal(np.array(r["relative_pose"])))
+            r["cur_frame_id"] = i
+            want_loops.append(r)
+    assert len(kmap) == len(rmap.frames) == sum(g["inserted"] for g in got)
+    assert [(l["cur_frame_id"], l["loop_frame_id"]) for l in loops] == [(l["cur_frame_id"], l["loop_frame_id"]) for l in want_loops]
+    assert len(loops) >= 2, "the way back must close loops on the way out"
+    for g, w in zip(loops, want_loops):
+        assert g["relative_pose"][:2] == pytest.approx(w["relative_pose"][:2], abs=1e-9)
+        assert abs(normalize_angle(g["relative_pose"][2] - w["relative_pose"][2])) < 1e-6
+        assert g["response"] == pytest.approx(w["response"], rel=5e-3)
+    with pytest.raises(N.NikError):
+        trk.attach_map(kmap, True)              # too late: the tracker has started
+    trk.close(); kmap.close(); flow.close()
