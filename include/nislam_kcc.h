@@ -249,6 +249,26 @@ int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, n
 int  nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop);
 int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);
 
+/* ---- 2-D pose-graph optimisation (MapBuilder::OptimizeMap, map_builder.cc:195-271) ------------------------
+ * The Ceres problem of src/optimization_2d/pose_graph_2d.cc:53-109,187-200 solved by an own Levenberg-Marquardt
+ * (host, double): residual = chol_lower(information) * [R(yaw_a)^T (p_b - p_a) - p_ab; Normalize(yaw_b - yaw_a -
+ * yaw_ab)], yaw updated through NormalizeAngle, the pose with id 0 constant.  Same minimum as Ceres (same cost,
+ * same LM scheme and tolerances); the iterates are not Ceres' bit for bit. */
+typedef struct {
+    int32_t id_begin, id_end;        /* Constraint2d (include/optimization_2d/types.h:80-96)                     */
+    double  x, y, yaw_radians;       /* pose of id_end in the frame of id_begin                                  */
+    double  information[9];          /* row-major symmetric positive-definite 3x3 (x, y, yaw)                    */
+} nik_pg_constraint;
+enum { NIK_PG_CONVERGENCE = 0, NIK_PG_NO_CONVERGENCE = 1, NIK_PG_FAILURE = 2, NIK_PG_NO_CONSTRAINTS = 3 };
+typedef struct {
+    int32_t termination;             /* NIK_PG_*: NO_CONVERGENCE = max_iterations reached (still usable)          */
+    int32_t iterations, successful_steps;
+    double  initial_cost, final_cost;   /* 0.5 * sum of squared residuals, as Ceres reports                       */
+} nik_pg_summary;
+/* poses: n_poses x (x, y, yaw), updated in place; ids: their frame ids (must contain 0); max_iterations <= 0: 300. */
+int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* poses, int n_constraints,
+                            const nik_pg_constraint* constraints, int max_iterations, nik_pg_summary* summary);
+
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on nik_stream() around every hot-path launch.

@@ -157,7 +157,20 @@ template <class P, bool INV> struct Dir {
 //   out: vout[v][q] = X[j + q*ML]          (valid for j < ML), natural order
 // All threads of the workgroup must call this (it contains barriers); the caller must place a barrier
 // between two chains that share an exchange buffer.
-template <class P, bool INV, int NV, int RFV, int RLV>
+// Synchronisation between the passes of a line.  When all threads of a line sit in ONE wavefront (WAVE: the
+// caller maps line = tid / T with T dividing 64), the LDS exchange needs no workgroup barrier: a wave's LDS
+// operations execute in order, so only the compiler has to be kept from reordering them.  The waves of a workgroup
+// then run their transforms independently (no lock-step with the slowest wave).
+template <bool WAVE> __device__ __forceinline__ void line_sync() {
+    if constexpr (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+template <class P, bool INV, int NV, bool WAVE = false, int RFV = 0, int RLV = 0>
 __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)[NV][RLV],
                                           unsigned j, float2* const (&ex)[NV], const float2* __restrict__ tw) {
     using D = Dir<P, INV>;
@@ -184,7 +197,7 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
             for (int q = 1; q < RM; ++q) w2[q] = tw[q * RF + k];
         }
-        __syncthreads();
+        line_sync<WAVE>();
         if (act) {
             const unsigned pj = D::phys(j);
 #pragma unroll
@@ -192,7 +205,7 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
                 for (int q = 0; q < RM; ++q) vm[v][q] = ex[v][pj + q * D::SM];
         }
-        __syncthreads();
+        line_sync<WAVE>();
         if (act) {
             // phys(jb*RF*RM + k + q*RF) = jb*(RF*RM + RM) + k + q*(RF+1)
             const unsigned wb = jb * (RF * RM + RM) + k;
@@ -214,7 +227,7 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
         for (int q = 1; q < RL; ++q) wl[q] = t[q * D::ML];
     }
-    __syncthreads();
+    line_sync<WAVE>();
     if (actl) {
         const unsigned pj = D::phys(j);
 #pragma unroll

@@ -52,6 +52,9 @@ PlanDesc plan_desc(int n_) {
 #ifndef KCC_GATHER_GROUP
 #define KCC_GATHER_GROUP 4
 #endif
+#ifndef KCC_WAVE_LOCAL
+#define KCC_WAVE_LOCAL 1
+#endif
 #ifndef KCC_ALX
 #define KCC_ALX 16
 #endif
@@ -428,6 +431,7 @@ template <int HH, int SRC>
 __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<HH>::WPS)) void kA_fwd(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
+    constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);   // lines are wave-local: no workgroup barriers inside the chain
     float2* lds = reinterpret_cast<float2*>(smem);
     if (a.ablate & 8) return;
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
@@ -499,7 +503,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         __syncthreads();                                     // table consumed before the exchange buffer is written
     }
     float2* const ex[1] = { lds + line * C::EPITCH };
-    fft_chain<P, false, 1>(vin, vout, j, ex, a.tw_f);
+    fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
     __syncthreads();                                         // exchange buffer fully consumed
     if (j < D::ML) {
 #pragma unroll
@@ -513,6 +517,7 @@ template <int HH, int EPI>
 __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = ICfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
+    constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
     constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
     if (a.ablate & 8) return;
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     }
     __syncthreads();                                         // natural buffer consumed before the exchange overwrites it
     float2* const ex[1] = { lds + line * C::EPITCH };
-    if (!(a.ablate & 4)) fft_chain<P, true, 1>(vin, vout, j, ex, a.tw_i);
+    if (!(a.ablate & 4)) fft_chain<P, true, 1, WL>(vin, vout, j, ex, a.tw_i);
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
 
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
             atomicMax(a.maxbuf + 2 * item + plane, __float_as_uint(m2));   // non-negative floats order as uints
         }
         float2 fout[1][DF::RL];
-        if (!(a.ablate & 4)) fft_chain<P, false, 1>(vout, fout, j, ex, a.tw_f);
+        if (!(a.ablate & 4)) fft_chain<P, false, 1, WL>(vout, fout, j, ex, a.tw_f);
         __syncthreads();
         if (j < DF::ML) {
 #pragma unroll

@@ -26,7 +26,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_tracker_attach_map", "nik_tracker_loops", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
 
 
 class NikConfig(C.Structure):
@@ -132,6 +132,7 @@ def load():
         L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
         L.nik_tracker_attach_map.argtypes = [P, P, I]
         L.nik_tracker_loops.argtypes = [P, P, I, P]
+        L.nik_pose_graph_optimize.argtypes = [I, P, P, I, P, I, P]
         L.nik_map_create.argtypes = [P, P, P]
         L.nik_map_destroy.argtypes = [P]
         L.nik_map_destroy.restype = None
@@ -427,6 +428,36 @@ class Tracker:
         n = C.c_int(0)
         self._L.nik_tracker_keyframes(self._t, _p(slots), len(slots), C.addressof(n))
         return slots[: n.value].tolist()
+
+
+class NikPgConstraint(C.Structure):
+    """Constraint2d (include/optimization_2d/types.h:80-96)"""
+    _fields_ = [("id_begin", C.c_int32), ("id_end", C.c_int32), ("x", C.c_double), ("y", C.c_double), ("yaw_radians", C.c_double),
+                ("information", C.c_double * 9)]
+
+
+class NikPgSummary(C.Structure):
+    _fields_ = [("termination", C.c_int32), ("iterations", C.c_int32), ("successful_steps", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+def pose_graph_optimize(ids, poses, constraints, max_iterations=300):
+    """MapBuilder::OptimizeMap's solve (pose_graph_2d.cc).  ids: frame ids (0 is held fixed); poses: (n, 3) x, y, yaw;
+    constraints: iterable of (id_begin, id_end, x, y, yaw, information 3x3).  Returns (optimised poses, summary dict).
+    Host only: needs the library but no GPU."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    out = np.array(poses, np.float64).reshape(len(ids), 3).copy()
+    cons = (NikPgConstraint * max(len(constraints), 1))()
+    for k, (a, b, x, y, yaw, info) in enumerate(constraints):
+        cons[k].id_begin, cons[k].id_end, cons[k].x, cons[k].y, cons[k].yaw_radians = int(a), int(b), x, y, yaw
+        cons[k].information[:] = list(np.asarray(info, np.float64).reshape(9))
+    sm = NikPgSummary()
+    rc = load().nik_pose_graph_optimize(len(ids), _p(ids), _p(out), len(constraints), C.cast(cons, C.c_void_p), int(max_iterations),
+                                        C.addressof(sm))
+    if rc:
+        raise NikError(rc, "nik_pose_graph_optimize: unknown pose id / no pose 0 / information not positive definite")
+    return out, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
+                     initial_cost=sm.initial_cost, final_cost=sm.final_cost)
 
 
 def loop_config(grid_scale=0.1, to_find_loop=True, frame_gap_thr=100, distance_thr=5.0, position_response_thr=60.0,
