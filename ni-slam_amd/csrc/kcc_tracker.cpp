@@ -4,6 +4,7 @@
 // No GPU code here; every registration goes through nik_track_batch_dev / nik_pose_batch.
 #include "../../include/nislam_kcc.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -48,6 +49,7 @@ struct nik_tracker {
     V3 last_cf_pose{}, last_cf_real_pose{}, last_pose{};
     std::vector<nik_frame> free_slots;
     std::vector<nik_frame> keyframes;
+    int spec_depth = 8;                      // frames registered speculatively per batch (adapts to the keyframe spacing)
     nik_map* map = nullptr;                  // optional (borrowed): keyframes are added to it and searched for loops
     int to_find_loop = 0;
     std::vector<nik_loop_result> loops;      // MapBuilder::_loop_matches (never cleared here: no optimiser consumes them)
@@ -195,31 +197,21 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     std::vector<nik_pose_result> res(n);
     std::vector<nik_frame> keys(n);
     int rc, start = 0;
-    bool have_spectra = false;               // spectra of frames [start, n) already on the device
-    const size_t fsz = (size_t)t->H * t->W;
-
-    if (!t->init) {
-        if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return rc;
-        have_spectra = true;
-        first_frame(t, slot[0], out[0]);
-        start = 1;
-    }
+    // the spectra of a frame do not depend on the keyframe: all n frames in one batch
+    if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return rc;
+    if (!t->init) { first_frame(t, slot[0], out[0]); start = 1; }
     while (start < n) {
-        const int m = n - start;
+        // Register the next `depth` frames against the current keyframe in one batch.  The registrations are
+        // speculative: they are valid up to and including the next inserted frame, the ones after it are redone
+        // against the new keyframe.  The depth follows the observed keyframe spacing (twice the last gap), so
+        // little work is thrown away while the batches stay as large as the sequence allows.
+        const int m = std::min(n - start, std::max(1, t->spec_depth));
         for (int i = 0; i < m; ++i) keys[i] = t->key_slot;
-        // register every remaining frame against the current keyframe in one batch (speculative: valid up to and
-        // including the next inserted frame)
-        if (!have_spectra) rc = nik_track_batch_dev(t->ctx, m, d_gray + (size_t)start * fsz, keys.data(), slot.data() + start, 1, res.data(), 1);
-        else rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data());
-        if (rc) return rc;
-        have_spectra = true;
-        int i = start;
-        while (i < n) {
-            const bool inserted = apply_result(t, res[i - start], slot[i], out[i]);
-            ++i;
-            if (inserted) break;             // the frames after it must be registered against the new keyframe
-        }
-        start = i;
+        if ((rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data()))) return rc;
+        int i = 0; bool inserted = false;
+        while (i < m && !inserted) { inserted = apply_result(t, res[i], slot[start + i], out[start + i]); ++i; }
+        t->spec_depth = inserted ? std::min(t->max_batch, std::max(4, 2 * i)) : std::min(t->max_batch, 2 * std::max(1, t->spec_depth));
+        start += i;
     }
     // recycle the slots of frames that did not become keyframes
     for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]);
