@@ -249,6 +249,25 @@ int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, n
 int  nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop);
 int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);
 
+/* ---- coarse-to-fine registration over an image pyramid (BASELINE config 3; NO reference counterpart) ----------
+ * nik_pose_batch_window  ComputePose (small-rotation mode) with the arg-max of both correlation surfaces restricted to
+ *                        the cyclic (2*radius+1)^2 window around centers[i] = {rot_row, rot_col, trans_row, trans_col}
+ *                        (surface indices; rotation rows: also around the 180-degree mirror row).  PSR moments still
+ *                        cover the whole surface.
+ * nik_downsample_u8_dev  2x2 box filter, rounded: n device images H x W -> H/2 x W/2 (ctx's geometry is the source's).
+ * nik_pyramid_*          `levels` contexts (level l: (H, W) >> l; polar (PD, PC) * {1, 2/3, 1/3, 1/6, ...}); track_dev
+ *                        registers n (key, current) pairs: the coarsest level globally, every finer level inside the
+ *                        window predicted from the level above.  res: [levels][n], level 0 first. */
+int  nik_pose_batch_window(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs, const int32_t* centers /*[n][4]*/,
+                           int radius, nik_pose_result* res);
+int  nik_downsample_u8_dev(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out);
+typedef struct nik_pyramid nik_pyramid;
+int  nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_batch, int device, nik_pyramid** out);
+void nik_pyramid_destroy(nik_pyramid* p);
+int  nik_pyramid_levels(const nik_pyramid* p, int* dims /* [levels][4]: H, W, PD, PC; may be NULL */);
+int  nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res);
+const char* nik_pyramid_last_error(const nik_pyramid* p, int level);
+
 /* ---- 2-D pose-graph optimisation (MapBuilder::OptimizeMap, map_builder.cc:195-271) ------------------------
  * The Ceres problem of src/optimization_2d/pose_graph_2d.cc:53-109,187-200 solved by an own Levenberg-Marquardt
  * (host, double): residual = chol_lower(information) * [R(yaw_a)^T (p_b - p_a) - p_ab; Normalize(yaw_b - yaw_a -

@@ -34,7 +34,9 @@ struct Family {                 // one plane geometry with its tables
 };
 
 // index arrays of one call (each cap_items ints)
-enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_TIMG = 3, IX_TKEY = 4, IX_ROTIDX = 5, IX_COUNT = 6 };
+enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_TIMG = 3, IX_TKEY = 4, IX_ROTIDX = 5,
+       IX_WRR = 6, IX_WRC = 7, IX_WTR = 8, IX_WTC = 9,       // arg-max window centres (rotation / translation surface), host-written
+       IX_COUNT = 10 };
 
 struct Call {                   // one in-flight call on a lane
     int* h_idx = nullptr;                                   // pinned staging, IX_COUNT * cap_items
@@ -43,6 +45,8 @@ struct Call {                   // one in-flight call on a lane
     bool busy = false;          // `done` has been recorded and not yet waited for
     bool has_pose = false; int n = 0, n_hyp = 1; nik_pose_result* res = nullptr;
 };
+
+struct Window { const int* row = nullptr; const int* col = nullptr; int radius = 0, mirror = 0; };   // arg-max window (device arrays)
 
 struct Lane {
     hipStream_t stream = nullptr;
@@ -443,7 +447,7 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false)
 // EstimateTrans (correlation_flow.cc:145-179) for n items.  X spectra: x_fwd ? forward of tmpA lines : arena.
 void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx, SurfaceResult* out, int* rot_index, int n_hyp,
-                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr) {
+                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr, Window win = Window()) {
     hipStream_t s = L.stream;
     const double xs_bytes = xstore ? n * Cb(f) : 0.0;        // x_fwd with xstore: the forward spectrum is written out too
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
@@ -472,8 +476,9 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
       launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max); }
     }
     const int nb = argmax_blocks(f.g);
-    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "argmax").c_str(), n * Cb(f));
-      launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, win.row ? "argmax_win" : "argmax").c_str(), n * Cb(f));
+      if (win.row) launch_A_inv_argmax_win(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror);
+      else launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
     launch_finalize(s, n, L.partials, c->partial_stride, nb, out, rot_index, n_hyp, c->PD);
 }
 
@@ -481,17 +486,22 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
 // Leaves raw surface results in the call's h_rot / h_trans (valid after its `done` event).
 // polar_in_tmpA: the current frames' polar spectra are still half-transformed in L.tmpA (enqueue_intermedium with
 // defer_polar_B): the rotation stage finishes them, stores them in the frame store (slots IX_DST) and uses them.
-int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_in_tmpA = false) {
+int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_in_tmpA = false, int win_radius = -1) {
     hipStream_t s = L.stream;
     const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
+    Window wrot, wtr;                       // coarse-to-fine: arg-max windows staged in IX_W* (win_radius >= 0)
+    if (win_radius >= 0) {
+        wrot.row = didx(L, IX_WRR); wrot.col = didx(L, IX_WRC); wrot.radius = win_radius; wrot.mirror = 1;
+        wtr.row = didx(L, IX_WTR); wtr.col = didx(L, IX_WTC); wtr.radius = win_radius; wtr.mirror = 0;
+    }
     // rotation stage: z = key polar spectrum, x = current polar spectrum
     if (polar_in_tmpA)
         enqueue_estimate(c, L, n, c->pol, true, L.tmpA, c->spec_max, nullptr,
                          c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp,
-                         c->arena_P, c->pol.spec_elems, didx(L, IX_DST));
+                         c->arena_P, c->pol.spec_elems, didx(L, IX_DST), wrot);
     else
     enqueue_estimate(c, L, n, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
-                     c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp);
+                     c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp, nullptr, 0, nullptr, wrot);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
     { Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
@@ -501,10 +511,10 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
         launch_B_fwd(s, nt, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
         enqueue_estimate(c, L, nt, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(L, IX_TKEY), L.trans_res, nullptr, 1);
+                         didx(L, IX_TKEY), L.trans_res, nullptr, 1, nullptr, 0, nullptr, wtr);
     } else {
         enqueue_estimate(c, L, nt, c->img, true, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
-                         didx(L, IX_TKEY), L.trans_res, nullptr, 1);
+                         didx(L, IX_TKEY), L.trans_res, nullptr, 1, nullptr, 0, nullptr, wtr);
     }
     HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * n, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipMemcpyAsync(L.cur->h_trans, L.trans_res, sizeof(SurfaceResult) * nt, hipMemcpyDeviceToHost, s));
@@ -852,7 +862,7 @@ static int ensure_kzz(nik_ctx* c, int n, const nik_frame* keys) {
 
 // shared body of nik_pose_batch / nik_track_batch_dev
 static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* keys, const nik_frame* curs,
-                     int not_large_rotation, nik_pose_result* res) {
+                     int not_large_rotation, nik_pose_result* res, const int32_t* win_centers = nullptr, int win_radius = -1) {
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
@@ -868,6 +878,14 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             else { if ((rc = depend_on_slot(c, L, li, curs[i]))) return rc; note_read(c, L, li, curs[i]); }
         }
         if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
+        if (win_centers) {
+            for (int i = 0; i < m; ++i) {
+                const int32_t* w = win_centers + 4 * (size_t)(b + i);
+                hidx(L, IX_WRR)[i] = w[0]; hidx(L, IX_WRC)[i] = w[1]; hidx(L, IX_WTR)[i] = w[2]; hidx(L, IX_WTC)[i] = w[3];
+            }
+            HIP_TRY(c, hipMemcpyAsync(L.d_idx + (size_t)L.cap_items * IX_WRR, L.cur->h_idx + (size_t)L.cap_items * IX_WRR,
+                                      sizeof(int) * (size_t)L.cap_items * 4, hipMemcpyHostToDevice, L.stream));
+        }
         bool fuse = false;
         if (d_gray) {
             enqueue_u8_to_plane(c, L, m, d_gray + (size_t)b * c->img.real_elems);
@@ -877,7 +895,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             enqueue_intermedium(c, L, m, fuse);
             if ((rc = mark_written(c, L, li, curs + b, m))) return rc;
         }
-        if ((rc = enqueue_pose(c, L, m, not_large_rotation, fuse))) return rc;
+        if ((rc = enqueue_pose(c, L, m, not_large_rotation, fuse, win_centers ? win_radius : -1))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
         if ((rc = end_call(c, L))) return rc;
@@ -895,6 +913,34 @@ int nik_pose_batch(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* cu
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
     if ((rc = pose_call(c, n, nullptr, keys, curs, not_large_rotation, res))) return rc;
     return drain_all(c);
+}
+
+int nik_pose_batch_window(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, const int32_t* centers, int radius,
+                          nik_pose_result* res) {
+    if (!c || !keys || !curs || !centers || n < 0 || radius < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    int rc;
+    if ((rc = check_kernel(c))) return rc;
+    if (n == 0) return NIK_OK;
+    if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
+    for (int i = 0; i < n; ++i) {
+        if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
+        const int32_t* w = centers + 4 * (size_t)i;
+        if (w[0] < 0 || w[0] >= c->PD || w[1] < 0 || w[1] >= c->PC || w[2] < 0 || w[2] >= c->H || w[3] < 0 || w[3] >= c->W)
+            return fail(c, NIK_ERR_INVALID_ARG, "window centre of pair %d outside its surface", i);
+    }
+    if ((rc = pose_call(c, n, nullptr, keys, curs, 1, res, centers, radius))) return rc;
+    return drain_all(c);
+}
+
+int nik_downsample_u8_dev(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_out) {
+    if (!c || !d_in || !d_out || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (n == 0) return NIK_OK;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    launch_downsample_u8(c->lanes[0].stream, n, d_in, d_out, c->H, c->W);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->lanes[0].stream));
+    return NIK_OK;
 }
 
 int nik_pose(nik_ctx* c, nik_frame key, nik_frame cur, int not_large_rotation, double pose[3], double info[3],

@@ -68,6 +68,8 @@ void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_o
 void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
                           const int16_t* map1, const uint16_t* map2, int H, int W);
 
+// 2 x 2 box-filtered half-resolution image (pyramid level)
+void launch_downsample_u8(hipStream_t s, int n, const uint8_t* in, uint8_t* out, int H, int W);
 // 8-bit RGB/BGR (interleaved) -> gray with OpenCV's integer luma weights
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr);
 
@@ -100,6 +102,10 @@ void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, 
 // inverse -> /(rows*cols) -> arg-max + moments partials
 void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                          Partial* partials, int partial_stride);
+// the same with the arg-max candidates restricted to a cyclic (2*radius+1)^2 window around (win_row[item], win_col[item])
+// (mirror: also around row + rows/2); the PSR moments still cover the whole surface
+void launch_A_inv_argmax_win(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                             Partial* partials, int partial_stride, const int* win_row, const int* win_col, int radius, int mirror);
 int  argmax_blocks(PlaneGeom g);
 
 // ---- B-type: contiguous spectrum lines along `cols` ----

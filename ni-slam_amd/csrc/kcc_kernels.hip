@@ -177,6 +177,18 @@ __global__ void k_rgb2gray(const uint8_t* __restrict__ rgb, uint8_t* __restrict_
     const int r = bgr ? p[2] : p[0], g = p[1], b = bgr ? p[0] : p[2];
     gray[i] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
 }
+// 2 x 2 box filter, rounded: one pyramid level (u8 row-major H x W -> H/2 x W/2); no reference counterpart
+__global__ void k_downsample_u8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W) {
+    const int Wo = W / 2, Ho = H / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, item = blockIdx.y;
+    if (i >= Ho * Wo) return;
+    const int r = i / Wo, c = i - r * Wo;
+    const uint8_t* p = in + (size_t)item * H * W + (size_t)(2 * r) * W + 2 * c;
+    out[(size_t)item * Ho * Wo + i] = (uint8_t)((p[0] + p[1] + p[W] + p[W + 1] + 2) >> 2);
+}
+void launch_downsample_u8(hipStream_t s, int n, const uint8_t* in, uint8_t* out, int H, int W) {
+    hipLaunchKernelGGL(k_downsample_u8, dim3(((H / 2) * (W / 2) + 255) / 256, n), dim3(256), 0, s, in, out, H, W);
+}
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr) {
     hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
 }
@@ -251,7 +263,8 @@ void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int*
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
 enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };
-enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4, EPI_SHIFTED = 5 };
+enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4, EPI_SHIFTED = 5,
+       EPI_ARGMAX_WIN = 6 };   // arg-max restricted to a cyclic window per item (coarse-to-fine registration)
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
 struct AArgs {
@@ -268,6 +281,7 @@ struct AArgs {
     // inverse outputs
     float* real_out; size_t real_stride;
     Partial* partials; int partial_stride;
+    const int* win_row; const int* win_col; int win_radius, win_mirror;   // ARGMAX_WIN: per-item window centre; mirror: also centre + rows/2
     KernelFn fn; unsigned* maxbuf; const float* energy;
 };
 
@@ -513,6 +527,14 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
     a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
 }
 
+// row r within `radius` (cyclically) of the window centre, or -- rotation surfaces, whose source is point-symmetric --
+// of the centre's 180-degree mirror row
+__device__ __forceinline__ bool win_hit(int r, int centre, int rows, int radius, int mirror) {
+    int d = abs(r - centre); d = min(d, rows - d);
+    if (mirror) { int m = abs(d - rows / 2); d = min(d, m); }
+    return d <= radius;
+}
+
 template <int HH, int EPI>
 __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -609,14 +631,27 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
         // arg-max (column-major first strict max, Eigen maxCoeff visitor) + moments for GetInfo
         float best = -INFINITY; int bidx = 0x7FFFFFFF;
         float s1 = 0.f, s2 = 0.f;
+        int wr = 0; bool in_col = true;
+        if (EPI == EPI_ARGMAX_WIN) {
+            wr = a.win_row[item];
+            int dc = abs(x0 + line - a.win_col[item]); dc = min(dc, a.cols - dc);
+            in_col = dc <= a.win_radius;
+        }
         if (j < DI::ML) {
             const int base = (x0 + line) * a.rows;
 #pragma unroll
             for (int q = 0; q < DI::RL; ++q) {               // increasing q -> increasing linear index
                 const float g0 = vout[0][q].x * rsize, g1 = vout[0][q].y * rsize;
                 const int li = base + 2 * (j + q * DI::ML);
-                if (g0 > best) { best = g0; bidx = li; }
-                if (g1 > best) { best = g1; bidx = li + 1; }
+                if (EPI == EPI_ARGMAX_WIN) {
+                    // candidates only inside the (2R+1)^2 cyclic window (the moments still cover the whole surface)
+                    const int r0 = 2 * (j + q * DI::ML);
+                    if (in_col && win_hit(r0, wr, a.rows, a.win_radius, a.win_mirror) && g0 > best) { best = g0; bidx = li; }
+                    if (in_col && win_hit(r0 + 1, wr, a.rows, a.win_radius, a.win_mirror) && g1 > best) { best = g1; bidx = li + 1; }
+                } else {
+                    if (g0 > best) { best = g0; bidx = li; }
+                    if (g1 > best) { best = g1; bidx = li + 1; }
+                }
                 s1 += g0 + g1; s2 += g0 * g0 + g1 * g1;
             }
         }
@@ -736,6 +771,15 @@ void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, 
         DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
     }
+}
+void launch_A_inv_argmax_win(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
+                             Partial* partials, int partial_stride, const int* win_row, const int* win_col, int radius, int mirror) {
+    AArgs a = base_args(g, t);
+    a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.partials = partials; a.partial_stride = partial_stride;
+    a.win_row = win_row; a.win_col = win_col; a.win_radius = radius; a.win_mirror = mirror;
+#define CALL(HH) launchA_inv_t<HH, EPI_ARGMAX_WIN>(s, n_items, 1, a)
+    DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
 }
 void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                          Partial* partials, int partial_stride) {

@@ -1,0 +1,118 @@
+// kcc_pyramid.cpp -- coarse-to-fine registration over an image pyramid: BASELINE config 3 ("4-level correlation
+// pyramid with radius-4 lookup").  NO REFERENCE COUNTERPART (the reference registers at one resolution); defined in
+// SURVEY 8(d) as an extension and checked against this repository's own CPU restatement only:
+//   level l image = 2x2 box filter (rounded) of level l-1;  level l polar size = (PD, PC) * {1, 2/3, 1/3, 1/6, ...};
+//   the coarsest level runs the plain KCC pose (small-rotation mode); every finer level runs it with the arg-max of
+//   both correlation surfaces restricted to the (2R+1)^2 cyclic window around the peak predicted by the level above
+//   (rotation surface: also around the 180-degree mirror row -- its source is point-symmetric).
+// One nik_ctx per level; host code only (the kernels are the ordinary ones plus the windowed arg-max).
+#include "../../include/nislam_kcc.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <cmath>
+#include <vector>
+
+struct nik_pyramid {
+    int levels = 0, max_batch = 0, H = 0, W = 0;
+    std::vector<nik_ctx*> ctx;                 // [level]
+    std::vector<int> h, w, pd, pc;
+    std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer)
+};
+
+namespace {
+
+// surface index of level `to` predicted from the peak index `idx` (0 <= idx < n_from) of level `from`: offsets from the
+// surface centre scale with the surface size
+int predict(int idx, int n_from, int n_to) {
+    const double off = (double)(idx - n_from / 2) * (double)n_to / (double)n_from;
+    long p = n_to / 2 + std::lround(off);
+    p %= n_to; if (p < 0) p += n_to;
+    return (int)p;
+}
+
+}  // namespace
+
+extern "C" {
+
+void nik_pyramid_destroy(nik_pyramid* p) {
+    if (!p) return;
+    for (nik_ctx* c : p->ctx) if (c) nik_destroy(c);
+    for (uint8_t* b : p->d_key) if (b) (void)hipFree(b);
+    for (uint8_t* b : p->d_cur) if (b) (void)hipFree(b);
+    delete p;
+}
+
+int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_batch, int device, nik_pyramid** out) {
+    if (!cfg || !out || levels < 1 || levels > 6 || max_batch < 1) return NIK_ERR_INVALID_ARG;
+    if ((H % (1 << levels)) || (W % (1 << levels))) return NIK_ERR_INVALID_ARG;      // every level keeps even sizes
+    nik_pyramid* p = new nik_pyramid();
+    p->levels = levels; p->max_batch = max_batch; p->H = H; p->W = W;
+    p->ctx.assign(levels, nullptr); p->d_key.assign(levels, nullptr); p->d_cur.assign(levels, nullptr);
+    for (int l = 0; l < levels; ++l) {
+        nik_config c = *cfg;
+        // polar geometry per level: 1, 2/3, 1/3, 1/6, ... of the base (720x480 -> 480x320 -> 240x160 -> 120x80)
+        const int num = l == 0 ? 3 : 2, den = l == 0 ? 3 : 3 << (l - 1);
+        if ((cfg->rotation_divisor * num) % den || (cfg->rotation_channel * num) % den) { nik_pyramid_destroy(p); return NIK_ERR_UNSUPPORTED_SIZE; }
+        c.rotation_divisor = cfg->rotation_divisor * num / den; c.rotation_channel = cfg->rotation_channel * num / den;
+        c.height = H >> l; c.width = W >> l;
+        p->h.push_back(H >> l); p->w.push_back(W >> l); p->pd.push_back(c.rotation_divisor); p->pc.push_back(c.rotation_channel);
+        const int rc = nik_create(&c, H >> l, W >> l, max_batch, 2 * max_batch, device, &p->ctx[l]);
+        if (rc) { nik_pyramid_destroy(p); return rc; }
+        if (l > 0) {
+            const size_t bytes = (size_t)max_batch * (H >> l) * (W >> l);
+            if (hipMalloc(&p->d_key[l], bytes) != hipSuccess || hipMalloc(&p->d_cur[l], bytes) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
+        }
+    }
+    *out = p;
+    return NIK_OK;
+}
+
+int nik_pyramid_levels(const nik_pyramid* p, int* dims /* [levels][4]: H, W, PD, PC */) {
+    if (!p) return 0;
+    if (dims) for (int l = 0; l < p->levels; ++l) { dims[4 * l] = p->h[l]; dims[4 * l + 1] = p->w[l]; dims[4 * l + 2] = p->pd[l]; dims[4 * l + 3] = p->pc[l]; }
+    return p->levels;
+}
+
+int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res) {
+    if (!p || !d_key || !d_cur || !res || n < 0 || radius < 0) return NIK_ERR_INVALID_ARG;
+    if (n == 0) return NIK_OK;
+    if (n > p->max_batch) return NIK_ERR_CAPACITY;
+    const int L = p->levels;
+    int rc;
+    std::vector<const uint8_t*> key(L), cur(L);
+    key[0] = d_key; cur[0] = d_cur;
+    for (int l = 1; l < L; ++l) {
+        if ((rc = nik_downsample_u8_dev(p->ctx[l - 1], n, key[l - 1], p->d_key[l])) ||
+            (rc = nik_downsample_u8_dev(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l]))) return rc;
+        key[l] = p->d_key[l]; cur[l] = p->d_cur[l];
+    }
+    std::vector<nik_frame> ks(n), cs(n);
+    for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; }
+    std::vector<int32_t> centers(4 * (size_t)n);
+    for (int l = L - 1; l >= 0; --l) {
+        nik_ctx* c = p->ctx[l];
+        nik_pose_result* out = res + (size_t)l * n;
+        if ((rc = nik_intermedium_batch_dev(c, n, key[l], ks.data()))) return rc;
+        if (l == L - 1) {
+            if ((rc = nik_track_batch_dev(c, n, cur[l], ks.data(), cs.data(), 1, out, 1))) return rc;
+        } else {
+            const nik_pose_result* up = res + (size_t)(l + 1) * n;
+            for (int i = 0; i < n; ++i) {
+                centers[4 * i + 0] = predict(up[i].rot_row, p->pd[l + 1], p->pd[l]);
+                centers[4 * i + 1] = predict(up[i].rot_col, p->pc[l + 1], p->pc[l]);
+                centers[4 * i + 2] = predict(up[i].trans_row[0], p->h[l + 1], p->h[l]);
+                centers[4 * i + 3] = predict(up[i].trans_col[0], p->w[l + 1], p->w[l]);
+            }
+            if ((rc = nik_intermedium_batch_dev(c, n, cur[l], cs.data())) ||
+                (rc = nik_pose_batch_window(c, n, ks.data(), cs.data(), centers.data(), radius, out))) return rc;
+        }
+    }
+    return NIK_OK;
+}
+
+const char* nik_pyramid_last_error(const nik_pyramid* p, int level) {
+    return (p && level >= 0 && level < p->levels) ? nik_last_error(p->ctx[level]) : "";
+}
+
+}  // extern "C"

@@ -26,7 +26,8 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
+           "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
 
 
 class NikConfig(C.Structure):
@@ -133,6 +134,15 @@ def load():
         L.nik_tracker_attach_map.argtypes = [P, P, I]
         L.nik_tracker_loops.argtypes = [P, P, I, P]
         L.nik_pose_graph_optimize.argtypes = [I, P, P, I, P, I, P]
+        L.nik_pose_batch_window.argtypes = [P, I, P, P, P, I, P]
+        L.nik_downsample_u8_dev.argtypes = [P, I, P, P]
+        L.nik_pyramid_create.argtypes = [P, I, I, I, I, I, P]
+        L.nik_pyramid_destroy.argtypes = [P]
+        L.nik_pyramid_destroy.restype = None
+        L.nik_pyramid_levels.argtypes = [P, P]
+        L.nik_pyramid_track_dev.argtypes = [P, I, P, P, I, P]
+        L.nik_pyramid_last_error.argtypes = [P, I]
+        L.nik_pyramid_last_error.restype = C.c_char_p
         L.nik_map_create.argtypes = [P, P, P]
         L.nik_map_destroy.argtypes = [P]
         L.nik_map_destroy.restype = None
@@ -308,6 +318,18 @@ class CorrelationFlow:
                                               int(bool(not_large_rotation)), C.cast(res, C.c_void_p), int(bool(sync))))
         return res
 
+    def pose_batch_window(self, keys, curs, centers, radius):
+        """ComputePose (small-rotation mode) with both arg-max searches restricted to windows; centers: (n, 4) int32."""
+        keys, curs = _i32(keys), _i32(curs)
+        n = len(keys)
+        centers = np.ascontiguousarray(centers, np.int32).reshape(n, 4)
+        res = (NikPoseResult * n)()
+        self._chk(self._L.nik_pose_batch_window(self._ctx, n, _p(keys), _p(curs), _p(centers), int(radius), C.cast(res, C.c_void_p)))
+        return res
+
+    def downsample_u8_dev(self, d_in_ptr, n, d_out_ptr):
+        self._chk(self._L.nik_downsample_u8_dev(self._ctx, int(n), C.c_void_p(int(d_in_ptr)), C.c_void_p(int(d_out_ptr))))
+
     def match(self, query, cands):
         cands = _i32(cands)
         n = len(cands)
@@ -458,6 +480,36 @@ def pose_graph_optimize(ids, poses, constraints, max_iterations=300):
         raise NikError(rc, "nik_pose_graph_optimize: unknown pose id / no pose 0 / information not positive definite")
     return out, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
                      initial_cost=sm.initial_cost, final_cost=sm.final_cost)
+
+
+class Pyramid:
+    """coarse-to-fine registration over an image pyramid (BASELINE config 3; no reference counterpart)"""
+
+    def __init__(self, cfg, H, W, levels=4, max_batch=32, device=0):
+        self._L = load()
+        self._p = C.c_void_p()
+        self.levels, self.max_batch = levels, max_batch
+        rc = self._L.nik_pyramid_create(C.byref(cfg), H, W, levels, max_batch, device, C.byref(self._p))
+        if rc:
+            raise NikError(rc, "nik_pyramid_create failed (unsupported level geometry?)")
+        d = np.zeros((levels, 4), np.int32)
+        self._L.nik_pyramid_levels(self._p, _p(d))
+        self.dims = d.tolist()                      # [level] -> [H, W, PD, PC]
+
+    def close(self):
+        if getattr(self, "_p", None):
+            self._L.nik_pyramid_destroy(self._p)
+            self._p = None
+
+    __del__ = close
+
+    def track_dev(self, d_key_ptr, d_cur_ptr, n, radius=4):
+        res = (NikPoseResult * (self.levels * n))()
+        rc = self._L.nik_pyramid_track_dev(self._p, int(n), C.c_void_p(int(d_key_ptr)), C.c_void_p(int(d_cur_ptr)), int(radius),
+                                           C.cast(res, C.c_void_p))
+        if rc:
+            raise NikError(rc, "; ".join(self._L.nik_pyramid_last_error(self._p, l).decode() for l in range(self.levels)))
+        return [[res[l * n + i].as_dict() for i in range(n)] for l in range(self.levels)]
 
 
 def loop_config(grid_scale=0.1, to_find_loop=True, frame_gap_thr=100, distance_thr=5.0, position_response_thr=60.0,

@@ -42,6 +42,9 @@ struct ora_ctx {
     ora_cf32* target_rotation_fft;  /* (PD/2+1) x PC correlation_flow.cc:43 */
     /* warpPolar maps (depend only on H, W, PD, PC) */
     float* mapx; float* mapy;
+    /* coarse-to-fine extension (BASELINE config 3, no reference counterpart): arg-max windows, [0] translation
+       surface, [1] rotation surface; radius < 0 = off */
+    int win_row[2], win_col[2], win_radius;
 };
 
 static inline ora_cf32 cmul(ora_cf32 a, ora_cf32 b) {
@@ -381,6 +384,7 @@ ora_ctx* ora_create(const ora_config* cfg, int image_height, int image_width) {
     ctx->cfg.height = image_height; ctx->cfg.width = image_width;
     ctx->H = image_height; ctx->W = image_width;
     ctx->PD = cfg->rotation_divisor; ctx->PC = cfg->rotation_channel;
+    ctx->win_radius = -1;
     ctx->target_fft = get_target_fft(ctx, ctx->H, ctx->W);
     ctx->target_rotation_fft = get_target_fft(ctx, ctx->PD, ctx->PC);
     build_polar_maps(ctx);
@@ -539,7 +543,21 @@ float ora_estimate_trans(ora_ctx* ctx, const ora_cf32* last_fft, const ora_cf32*
     ora_ifft(ctx, Kzz, hr, width, g);
     /* :175 g.maxCoeff(&row,&col): Eigen visitor, column-major traversal, first strict max [recalled] */
     long best = 0; float response = g[0];
-    for (long i = 1; i < n; ++i) if (g[i] > response) { response = g[i]; best = i; }
+    if (ctx->win_radius < 0) {
+        for (long i = 1; i < n; ++i) if (g[i] > response) { response = g[i]; best = i; }
+    } else {
+        /* extension: the same traversal, candidates only inside the cyclic window (rotation surface: also around
+           the 180-degree mirror row of the window centre) */
+        const int R = ctx->win_radius, wr = ctx->win_row[which ? 1 : 0], wc = ctx->win_col[which ? 1 : 0];
+        best = -1; response = -INFINITY;
+        for (long i = 0; i < n; ++i) {
+            const int r = (int)(i % height), c = (int)(i / height);
+            int dc = abs(c - wc); if (width - dc < dc) dc = width - dc;
+            int dr = abs(r - wr); if (height - dr < dr) dr = height - dr;
+            if (which) { const int m = abs(dr - height / 2); if (m < dr) dr = m; }
+            if (dc <= R && dr <= R && g[i] > response) { response = g[i]; best = i; }
+        }
+    }
     const int row = (int)(best % height), col = (int)(best / height);
     trans[0] = -(row - height / 2);
     trans[1] = -(col - width / 2);
@@ -751,5 +769,23 @@ void ora_remap_u8(const uint8_t* src, int width, int height, const int16_t* map1
                 if (sx + 1 >= 0 && sx + 1 < width) acc += w11 * src[(size_t)(sy + 1) * width + sx + 1];
             }
             dst[(size_t)i * width + j] = (uint8_t)((acc + (1 << 14)) >> 15);   /* FixedPtCast<int, uchar, 15> */
+        }
+}
+
+/* ======================================================================================================
+ * Coarse-to-fine extension (BASELINE config 3; NO reference counterpart -- defined in SURVEY 8(d))
+ * ====================================================================================================== */
+void ora_set_window(ora_ctx* ctx, int rot_row, int rot_col, int trans_row, int trans_col, int radius) {
+    ctx->win_row[1] = rot_row; ctx->win_col[1] = rot_col; ctx->win_row[0] = trans_row; ctx->win_col[0] = trans_col;
+    ctx->win_radius = radius;                /* radius < 0: plain global arg-max again */
+}
+
+/* 2 x 2 box filter, rounded: u8 row-major (height x width) -> (height/2 x width/2) */
+void ora_downsample_u8(const uint8_t* src, int width, int height, uint8_t* dst) {
+    const int wo = width / 2, ho = height / 2;
+    for (int r = 0; r < ho; ++r)
+        for (int c = 0; c < wo; ++c) {
+            const uint8_t* p = src + (size_t)(2 * r) * width + 2 * c;
+            dst[(size_t)r * wo + c] = (uint8_t)((p[0] + p[1] + p[width] + p[width + 1] + 2) >> 2);
         }
 }

@@ -134,6 +134,12 @@ void ora_undistort_maps(const double K[4], const double D[5], const double newK[
 void ora_remap_u8(const uint8_t* src_rowmajor, int width, int height, const int16_t* map1, const uint16_t* map2,
                   uint8_t* dst_rowmajor);
 
+/* ---- coarse-to-fine extension (BASELINE config 3; no reference counterpart): restrict the arg-max of the next
+ * ora_estimate_trans / ora_compute_pose calls to cyclic (2*radius+1)^2 windows (rotation surface: also around the
+ * mirror row); radius < 0 switches it off.  2x2 box down-sampling of a u8 image. */
+void ora_set_window(ora_ctx* ctx, int rot_row, int rot_col, int trans_row, int trans_col, int radius);
+void ora_downsample_u8(const uint8_t* src_rowmajor, int width, int height, uint8_t* dst_rowmajor);
+
 #ifdef __cplusplus
 }
 #endif

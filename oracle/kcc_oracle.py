@@ -81,6 +81,8 @@ def lib():
         L.ora_optimal_new_camera_matrix.argtypes = [P, P, C.c_int, C.c_int, P]
         L.ora_undistort_maps.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
         L.ora_remap_u8.argtypes = [P, C.c_int, C.c_int, P, P, P]
+        L.ora_set_window.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ora_downsample_u8.argtypes = [P, C.c_int, C.c_int, P]
         _lib = L
     return _lib
 
@@ -109,6 +111,10 @@ class Oracle:
         if getattr(self, "_ctx", None):
             lib().ora_destroy(self._ctx)
             self._ctx = None
+
+    def set_window(self, rot_row, rot_col, trans_row, trans_col, radius):
+        """coarse-to-fine extension: restrict both arg-max searches of the following calls (radius < 0: off)"""
+        lib().ora_set_window(self._ctx, int(rot_row), int(rot_col), int(trans_row), int(trans_col), int(radius))
 
     @staticmethod
     def normalize_u8(img):
@@ -241,4 +247,13 @@ def remap_u8(img, map1, map2):
     H, W = img.shape
     out = np.empty((H, W), np.uint8)
     lib().ora_remap_u8(_p(img), W, H, _p(np.ascontiguousarray(map1, np.int16)), _p(np.ascontiguousarray(map2, np.uint16)), _p(out))
+    return out
+
+
+def downsample_u8(img):
+    """2 x 2 box filter, rounded (pyramid level of the coarse-to-fine extension)"""
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.empty((H // 2, W // 2), np.uint8)
+    lib().ora_downsample_u8(_p(img), W, H, _p(out))
     return out
