@@ -249,6 +249,23 @@ int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, n
 int  nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop);
 int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);
 
+/* ---- MapStitcher (src/map_stitcher.cc, include/map_stitcher.h): occupancy map of the key frames -----------------
+ * Cells are cell_size x cell_size int32 planes (data, weight), row-major [y in cell][x in cell], addressed by the
+ * reference's floor-divided (cell_x, cell_y).  The reference's arithmetic is kept literally (a cell's first frame
+ * stores raw sums and counts; later frames blend data*weight + sum*count and divide by the new weight).
+ * insert_dev   MapStitcher::InsertFrame: d_image = the undistorted u8 frame (device, row-major H x W; copied);
+ *              image_pose = the frame's pose in the image plane, centre based (ConvertRobotPoseToImagePlane +
+ *              ConvertPrincipalToCenter, map_stitcher.cc:40-42 -- the caller's camera math).
+ * recompute    MapStitcher::RecomputeOccupancy after a pose-graph update: new image poses for the listed frames, then
+ *              every stored frame replayed in ascending frame id (the reference's order is unspecified). */
+typedef struct nik_stitcher nik_stitcher;
+int  nik_stitcher_create(nik_ctx* ctx, int cell_size, nik_stitcher** out);
+void nik_stitcher_destroy(nik_stitcher* s);
+int  nik_stitcher_insert_dev(nik_stitcher* s, int frame_id, const uint8_t* d_image, const double image_pose[3]);
+int  nik_stitcher_recompute(nik_stitcher* s, int n, const int32_t* frame_ids, const double* image_poses /*[n][3]*/);
+int  nik_stitcher_cells(const nik_stitcher* s, int32_t* locs /*[cap][2]: cell_x, cell_y*/, int cap, int* n);
+int  nik_stitcher_read_cell(const nik_stitcher* s, int cell_x, int cell_y, int32_t* data, int32_t* weight);
+
 /* ---- coarse-to-fine registration over an image pyramid (BASELINE config 3; NO reference counterpart) ----------
  * nik_pose_batch_window  ComputePose (small-rotation mode) with the arg-max of both correlation surfaces restricted to
  *                        the cyclic (2*radius+1)^2 window around centers[i] = {rot_row, rot_col, trans_row, trans_col}

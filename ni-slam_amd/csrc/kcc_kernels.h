@@ -68,6 +68,12 @@ void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_o
 void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
                           const int16_t* map1, const uint16_t* map2, int H, int W);
 
+// MapStitcher::AddImageToOccupancy (map_stitcher.cc:36-133): frame -> temporary cells, temporary cell -> map cell
+struct StitchPose { double r00, r01, r10, r11, x, y, cx, cy; };   // RotationMatrix2D(theta), image pose, image centre (W/2, H/2)
+void launch_stitch_scatter(hipStream_t s, const uint8_t* img, int H, int W, const StitchPose& P, int size, int cx0, int cy0,
+                           int ncx, int ncy, int* tmp_data, int* tmp_weight);
+void launch_stitch_touched(hipStream_t s, const int* tmp_weight, int n_cells, int csz, int* flags);
+void launch_stitch_merge(hipStream_t s, int* data, int* weight, const int* tmp_data, const int* tmp_weight, int n, int existing);
 // 2 x 2 box-filtered half-resolution image (pyramid level)
 void launch_downsample_u8(hipStream_t s, int n, const uint8_t* in, uint8_t* out, int H, int W);
 // 8-bit RGB/BGR (interleaved) -> gray with OpenCV's integer luma weights

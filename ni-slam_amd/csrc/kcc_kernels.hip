@@ -260,6 +260,67 @@ void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int*
 }
 
 // ------------------------------------------------------------------------------------------------
+// MapStitcher::AddImageToOccupancy (map_stitcher.cc:36-133): scatter of one key frame into the occupancy cells
+// ------------------------------------------------------------------------------------------------
+// MapStitcher::ComputeCellPosition (map_stitcher.cc:24-34): floor division into (cell, position in cell)
+__device__ __forceinline__ void cell_position(int x, int size, int& cell, int& pos) {
+    cell = x >= 0 ? x / size : (x - size + 1) / size;
+    pos = x - cell * size;
+}
+// one thread per source pixel (i = column, j = row): map position = trunc(R * (i - cx, j - cy) + t), evaluated in
+// double exactly as the reference's Eigen expressions ((R00 * (i - cx) + X) + R01 * (j - cy), no contraction);
+// data += 100/255-scaled pixel, weight += 1 in the frame's temporary cells (tmp_data / tmp_weight of cell k at k * size^2)
+__global__ void k_stitch_scatter(const uint8_t* __restrict__ img, int H, int W, StitchPose P, int size,
+                                 int cx0, int cy0, int ncx, int ncy, int* __restrict__ tmp_data, int* __restrict__ tmp_weight) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+    if (i >= W) return;
+    const double wi = (double)i - P.cx, hj = (double)j - P.cy;
+    const int x = (int)((P.r00 * wi + P.x) + P.r01 * hj);
+    const int y = (int)((P.r10 * wi + P.y) + P.r11 * hj);
+    int gx, px, gy, py;
+    cell_position(x, size, gx, px); cell_position(y, size, gy, py);
+    const int k = (gx - cx0) * ncy + (gy - cy0);                   // the frame's cell grid is built from its corner pixels
+    if (gx < cx0 || gx >= cx0 + ncx || gy < cy0 || gy >= cy0 + ncy) return;   // (cannot happen for a rotated rectangle)
+    const size_t e = (size_t)k * size * size + (size_t)py * size + px;
+    // cv::Mat(u8) * (100.0 / 255.0): saturate_cast<uchar>(v * scale), round to nearest (no exact halves exist)
+    const int v = (int)__float2int_rn((float)((double)img[(size_t)j * W + i] * (100.0 / 255.0)));
+    atomicAdd(tmp_data + e, v);
+    atomicAdd(tmp_weight + e, 1);
+}
+// merge of one temporary cell into the map cell (map_stitcher.cc:113-131), literally:
+//   existing cell: data = data * weight + tmp.data * tmp.weight; weight += tmp.weight; data /= weight where weight >= 1
+//   new cell:      data = tmp.data; weight = tmp.weight
+__global__ void k_stitch_merge(int* __restrict__ data, int* __restrict__ weight, const int* __restrict__ tmp_data,
+                               const int* __restrict__ tmp_weight, int n, int existing) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (existing) {
+        const int d = data[e] * weight[e] + tmp_data[e] * tmp_weight[e];
+        const int w = weight[e] + tmp_weight[e];
+        weight[e] = w;
+        data[e] = w < 1 ? d : d / w;
+    } else {
+        data[e] = tmp_data[e]; weight[e] = tmp_weight[e];
+    }
+}
+// flags[k] = 1 iff temporary cell k received any pixel
+__global__ void k_stitch_touched(const int* __restrict__ tmp_weight, int csz, int* __restrict__ flags) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (e < csz && tmp_weight[(size_t)k * csz + e] != 0) flags[k] = 1;
+}
+void launch_stitch_touched(hipStream_t s, const int* tmp_weight, int n_cells, int csz, int* flags) {
+    hipLaunchKernelGGL(k_stitch_touched, dim3((csz + 255) / 256, n_cells), dim3(256), 0, s, tmp_weight, csz, flags);
+}
+void launch_stitch_scatter(hipStream_t s, const uint8_t* img, int H, int W, const StitchPose& P, int size, int cx0, int cy0,
+                           int ncx, int ncy, int* tmp_data, int* tmp_weight) {
+    hipLaunchKernelGGL(k_stitch_scatter, dim3((W + 255) / 256, H), dim3(256), 0, s, img, H, W, P, size, cx0, cy0, ncx, ncy, tmp_data, tmp_weight);
+}
+void launch_stitch_merge(hipStream_t s, int* data, int* weight, const int* tmp_data, const int* tmp_weight, int n, int existing) {
+    hipLaunchKernelGGL(k_stitch_merge, dim3((n + 255) / 256), dim3(256), 0, s, data, weight, tmp_data, tmp_weight, n, existing);
+}
+
+// ------------------------------------------------------------------------------------------------
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
 enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };

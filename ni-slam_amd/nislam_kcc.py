@@ -26,7 +26,8 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
            "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
+           "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
 
 
@@ -134,6 +135,13 @@ def load():
         L.nik_tracker_attach_map.argtypes = [P, P, I]
         L.nik_tracker_loops.argtypes = [P, P, I, P]
         L.nik_pose_graph_optimize.argtypes = [I, P, P, I, P, I, P]
+        L.nik_stitcher_create.argtypes = [P, I, P]
+        L.nik_stitcher_destroy.argtypes = [P]
+        L.nik_stitcher_destroy.restype = None
+        L.nik_stitcher_insert_dev.argtypes = [P, I, P, P]
+        L.nik_stitcher_recompute.argtypes = [P, I, P, P]
+        L.nik_stitcher_cells.argtypes = [P, P, I, P]
+        L.nik_stitcher_read_cell.argtypes = [P, I, I, P, P]
         L.nik_pose_batch_window.argtypes = [P, I, P, P, P, I, P]
         L.nik_downsample_u8_dev.argtypes = [P, I, P, P]
         L.nik_pyramid_create.argtypes = [P, I, I, I, I, I, P]
@@ -480,6 +488,48 @@ def pose_graph_optimize(ids, poses, constraints, max_iterations=300):
         raise NikError(rc, "nik_pose_graph_optimize: unknown pose id / no pose 0 / information not positive definite")
     return out, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
                      initial_cost=sm.initial_cost, final_cost=sm.final_cost)
+
+
+class Stitcher:
+    """MapStitcher (map_stitcher.cc): occupancy map of key frames on the device"""
+
+    def __init__(self, flow, cell_size=1000):
+        self._flow, self._L, self.cell_size = flow, flow._L, cell_size
+        self._s = C.c_void_p()
+        rc = self._L.nik_stitcher_create(flow._ctx, int(cell_size), C.byref(self._s))
+        if rc:
+            raise NikError(rc, "nik_stitcher_create failed")
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._L.nik_stitcher_destroy(self._s)
+            self._s = None
+
+    __del__ = close
+
+    def _chk(self, rc):
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode() or "stitcher call failed")
+
+    def insert_dev(self, frame_id, d_image_ptr, image_pose):
+        pose = np.ascontiguousarray(image_pose, np.float64)
+        self._chk(self._L.nik_stitcher_insert_dev(self._s, int(frame_id), C.c_void_p(int(d_image_ptr)), _p(pose)))
+
+    def recompute(self, frame_ids, image_poses):
+        ids = np.ascontiguousarray(frame_ids, np.int32); poses = np.ascontiguousarray(image_poses, np.float64).reshape(len(ids), 3)
+        self._chk(self._L.nik_stitcher_recompute(self._s, len(ids), _p(ids), _p(poses)))
+
+    def cells(self):
+        n = C.c_int(0)
+        self._L.nik_stitcher_cells(self._s, None, 0, C.addressof(n))
+        locs = np.zeros((max(n.value, 1), 2), np.int32)
+        self._L.nik_stitcher_cells(self._s, _p(locs), n.value, C.addressof(n))
+        return [tuple(int(v) for v in locs[i]) for i in range(n.value)]
+
+    def read_cell(self, cx, cy):
+        d = np.empty((self.cell_size, self.cell_size), np.int32); w = np.empty_like(d)
+        self._chk(self._L.nik_stitcher_read_cell(self._s, int(cx), int(cy), _p(d), _p(w)))
+        return d, w
 
 
 class Pyramid:
