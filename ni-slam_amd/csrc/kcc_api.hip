@@ -81,6 +81,7 @@ struct nik_ctx {
     Family img, pol;
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
     float* arena_img = nullptr; float2* arena_F = nullptr; float2* arena_P = nullptr;
+    int img_pitch = 0; size_t img_stride = 0;   // image planes: column pitch >= H + 4 (rows H..H+3 repeat rows 0..3), elements per slot
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
     // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
     bool kzz_cache = false;
@@ -413,10 +414,10 @@ inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // 
 void enqueue_u8_to_plane(nik_ctx* c, Lane& L, int m, const uint8_t* d_u8) {
     if (c->ud_map1) {
         Stage st(c, L, "k_undistort_cvt", m * (1.0 * c->img.real_elems + Rb(c->img)) + 6.0 * c->img.real_elems);
-        launch_undistort_cvt(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->ud_map1, c->ud_map2, c->H, c->W);
+        launch_undistort_cvt(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->ud_map1, c->ud_map2, c->H, c->W, c->img_pitch);
     } else {
         Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
-        launch_cvt_u8(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->H, c->W);
+        launch_cvt_u8(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->H, c->W, c->img_pitch);
     }
 }
 
@@ -430,7 +431,7 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false)
     const int* dst = didx(L, IX_DST);
     const Family& I = c->img; const Family& P = c->pol;
     { Stage st(c, L, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
-      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img.real_elems, dst, L.tmpA, c->spec_max); }
+      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max); }
     { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
                            L.gbuf, c->spec_max); }
@@ -505,7 +506,7 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
     { Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
-      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img.real_elems, didx(L, IX_TIMG), c->rot_tab,
+      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_tab,
                        didx(L, IX_ROTIDX), L.tmpA, c->spec_max); }
     if (c->cfg.kernel == 1) {
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
@@ -624,7 +625,12 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->s_elems = (size_t)(W + 1) * (H + 2);
     c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
     c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
-    TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img.real_elems * max_frames));
+    // column pitch: >= H + 4 (wrap rows), a multiple of 32 floats (columns start on 128-byte lines) and an ODD multiple
+    // (no power-of-two stride across HBM channels)
+    c->img_pitch = ((H + 4 + 31) / 32) * 32;
+    if (((c->img_pitch / 32) & 1) == 0) c->img_pitch += 32;
+    c->img_stride = (size_t)W * c->img_pitch;
+    TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img_stride * max_frames));
     TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_KzF, sizeof(float2) * c->img.spec_elems * max_frames));
@@ -763,8 +769,9 @@ int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {
     if ((rc = drain_all(c)) || (rc = check_slot(c, dst, false))) return rc;
     Lane& L = c->lanes[0];
     if ((rc = begin_call(c, L)) || (rc = depend_for_write(c, L, 0, dst))) return rc;
-    HIP_TRY(c, hipMemcpyAsync(c->arena_img + (size_t)dst * c->img.real_elems, image, sizeof(float) * c->img.real_elems,
-                              hipMemcpyHostToDevice, L.stream));
+    HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)dst * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
+                                sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, L.stream));
+    launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);
     hidx(L, IX_DST)[0] = dst;
     if ((rc = upload_idx(c, L, IX_DST, 1))) return rc;
     enqueue_intermedium(c, L, 1);
@@ -778,7 +785,8 @@ int nik_frame_export(nik_ctx* c, nik_frame f, float* image, float* fft_result, f
     int rc;
     if ((rc = nik_synchronize(c)) || (rc = check_slot(c, f, true))) return rc;
     hipStream_t s = c->lanes[0].stream;
-    if (image) HIP_TRY(c, hipMemcpyAsync(image, c->arena_img + (size_t)f * c->img.real_elems, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
+    if (image) HIP_TRY(c, hipMemcpy2DAsync(image, sizeof(float) * c->H, c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch,
+                                           sizeof(float) * c->H, c->W, hipMemcpyDeviceToHost, s));
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
     if (fft_result) {     // internal [hr][W] -> reference column-major (hr x W) == [W][hr]
         launch_transpose_c(s, c->arena_F + (size_t)f * c->img.spec_elems, scratch, c->img.g.hr, c->W);
@@ -799,7 +807,12 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
     if ((rc = nik_synchronize(c)) || (rc = check_slot(c, f, false))) return rc;
     hipStream_t s = c->lanes[0].stream;
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
-    if (image) { HIP_TRY(c, hipMemcpyAsync(c->arena_img + (size_t)f * c->img.real_elems, image, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s)); c->slot_ready[f] |= 1; }
+    if (image) {
+        HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
+                                    sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, s));
+        launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
+        c->slot_ready[f] |= 1;
+    }
     if (fft_result) {
         HIP_TRY(c, hipMemcpyAsync(scratch, fft_result, sizeof(float2) * c->img.spec_elems, hipMemcpyHostToDevice, s));
         launch_transpose_c(s, scratch, c->arena_F + (size_t)f * c->img.spec_elems, c->W, c->img.g.hr);
@@ -1115,7 +1128,7 @@ int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     float* d_in = c->d_scratch;                                                   // first half: real input
     float2* d_out = reinterpret_cast<float2*>(c->d_scratch) + c->spec_max;        // second half: transposed output
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * f.real_elems, hipMemcpyHostToDevice, s));
-    launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, nullptr, L.tmpA, c->spec_max);
+    launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, f.g.rows, nullptr, L.tmpA, c->spec_max);
     launch_B_fwd(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
     launch_transpose_c(s, L.tmpA, d_out, f.g.hr, f.g.cols);
     HIP_TRY(c, hipMemcpyAsync(xf_out, d_out, sizeof(float2) * f.spec_elems, hipMemcpyDeviceToHost, s));
@@ -1152,7 +1165,7 @@ int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     rotation_terms(c->H, c->W, (float)degree2 * 0.5f, terms.data());             // RotateArray(image, degree2/2)
     int* d_terms = reinterpret_cast<int*>(L.gbuf);
     HIP_TRY(c, hipMemcpyAsync(d_terms, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
-    launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img.real_elems, d_terms, c->d_scratch, c->H, c->W);
+    launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img_stride, d_terms, c->d_scratch, c->H, c->W, c->img_pitch);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());

@@ -60,13 +60,15 @@ PlanDesc plan_desc(int n);
 PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for half length n
 
 // ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
+// image planes have column pitch PH >= H + 4 (rows H..H+3 repeat rows 0..3: vertical wrap taps are contiguous)
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,
-                   int H, int W);
+                   int H, int W, int PH);
+void launch_img_wrap(hipStream_t s, float* img, int H, int W, int PH);     // refresh the wrap rows of one plane
 // Camera::UndistortImage (camera.cc:92-93): cv::remap with the fixed-point maps; u8 -> u8, and fused with the
 // u8 -> f32 column-major / 255 conversion (raw camera frame straight into the image arena)
 void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W);
 void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
-                          const int16_t* map1, const uint16_t* map2, int H, int W);
+                          const int16_t* map1, const uint16_t* map2, int H, int W, int PH);
 
 // MapStitcher::AddImageToOccupancy (map_stitcher.cc:36-133): frame -> temporary cells, temporary cell -> map cell
 struct StitchPose { double r00, r01, r10, r11, x, y, cx, cy; };   // RotationMatrix2D(theta), image pose, image centre (W/2, H/2)
@@ -81,10 +83,10 @@ void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t np
 
 // ---- A-type: lines along `rows` (r2c / c2r), transposed spectrum access ----
 // forward from a real plane: src plane index = src_idx ? src_idx[item] : item
-void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride,
+void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride, int src_pitch,
                         const int* src_idx, float2* dst, size_t dst_stride);
 // forward from the de-rotated image (RotateArray fused into the load)
-void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride,
+void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride, int img_pitch,
                       const int* img_slot, const int* rot_tab, const int* rot_index,
                       float2* dst, size_t dst_stride);
 // forward from polar(S), S = shifted zero-bordered planes [W+1][H+2] (gather fused into the load); g = polar geometry
@@ -160,7 +162,7 @@ void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int pa
                      SurfaceResult* out, int* rot_index, int n_hyp, int PD);
 
 // debug: the two gathers on their own (no FFT)
-void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W);
+void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W, int PH);
 void launch_dbg_polar(hipStream_t s, const float* S, const uint32_t* tab, float* out, int H, int W, int PD, int PC);
 
 // layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]

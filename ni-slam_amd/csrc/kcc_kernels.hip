@@ -142,12 +142,14 @@ __device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& i
 // ------------------------------------------------------------------------------------------------
 // 64 x 64 tile per workgroup: rows are read as uchar4 (64-byte row segments), transposed through LDS and written
 // as float4 along y (256-byte column segments).  Requires W % 4 == 0 and H % 4 == 0 (always true here).
+// Image planes are stored with column pitch PH >= H + 4: rows H..H+3 of a column repeat its rows 0..3, so a vertical
+// BORDER_WRAP tap pair (H-1, 0) is one contiguous 8-byte load (rot_sample).
 __global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
-                                                float* __restrict__ arena, int H, int W) {
+                                                float* __restrict__ arena, int H, int W, int PH) {
     __shared__ float tile[64][65];                          // [x][y], odd pitch
     const int item = blockIdx.z, tid = threadIdx.x;
     const uint8_t* in = src + (size_t)item * H * W;
-    float* out = arena + (size_t)dst_slot[item] * H * W;
+    float* out = arena + (size_t)dst_slot[item] * PH * W;
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -164,8 +166,11 @@ __global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src,
     for (int it = 0; it < 4; ++it) {
         const int x = (tid >> 4) + 16 * it, y = 4 * (tid & 15);
         const int c = c0 + x, r = r0 + y;
-        if (c < W && r < H)
-            *reinterpret_cast<float4*>(out + (size_t)c * H + r) = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
+        if (c < W && r < H) {
+            const float4 v = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
+            *reinterpret_cast<float4*>(out + (size_t)c * PH + r) = v;
+            if (r == 0) *reinterpret_cast<float4*>(out + (size_t)c * PH + H) = v;      // wrap rows
+        }
     }
 }
 
@@ -193,9 +198,17 @@ void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t np
     hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
 }
 
-void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img, int H, int W) {
+void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img, int H, int W, int PH) {
     dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
-    hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, d_gray, d_dst_slot, arena_img, H, W);
+    hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, d_gray, d_dst_slot, arena_img, H, W, PH);
+}
+// rows 0..3 of every column copied behind row H-1 (after a host import of a plane)
+__global__ void k_img_wrap(float* __restrict__ img, int H, int W, int PH) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < W) *reinterpret_cast<float4*>(img + (size_t)c * PH + H) = *reinterpret_cast<const float4*>(img + (size_t)c * PH);
+}
+void launch_img_wrap(hipStream_t s, float* img, int H, int W, int PH) {
+    hipLaunchKernelGGL(k_img_wrap, dim3((W + 255) / 256), dim3(256), 0, s, img, H, W, PH);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,11 +237,11 @@ __global__ __launch_bounds__(256) void k_undistort_u8(const uint8_t* __restrict_
 // raw u8 row-major -> undistorted f32 column-major / 255: k_cvt_u8 with the remap fused into its load
 __global__ __launch_bounds__(256) void k_undistort_cvt(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
                                                        float* __restrict__ arena, const short2* __restrict__ map1,
-                                                       const uint16_t* __restrict__ map2, int H, int W) {
+                                                       const uint16_t* __restrict__ map2, int H, int W, int PH) {
     __shared__ float tile[64][65];                          // [x][y], odd pitch
     const int item = blockIdx.z, tid = threadIdx.x;
     const uint8_t* in = src + (size_t)item * H * W;
-    float* out = arena + (size_t)dst_slot[item] * H * W;
+    float* out = arena + (size_t)dst_slot[item] * PH * W;
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
@@ -244,8 +257,11 @@ __global__ __launch_bounds__(256) void k_undistort_cvt(const uint8_t* __restrict
     for (int it = 0; it < 4; ++it) {
         const int x = (tid >> 4) + 16 * it, y = 4 * (tid & 15);
         const int c = c0 + x, r = r0 + y;
-        if (c < W && r < H)
-            *reinterpret_cast<float4*>(out + (size_t)c * H + r) = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
+        if (c < W && r < H) {
+            const float4 v = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
+            *reinterpret_cast<float4*>(out + (size_t)c * PH + r) = v;
+            if (r == 0) *reinterpret_cast<float4*>(out + (size_t)c * PH + H) = v;      // wrap rows
+        }
     }
 }
 void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W) {
@@ -253,10 +269,10 @@ void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_o
                        reinterpret_cast<const short2*>(map1), map2, H, W);
 }
 void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
-                          const int16_t* map1, const uint16_t* map2, int H, int W) {
+                          const int16_t* map1, const uint16_t* map2, int H, int W, int PH) {
     dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
     hipLaunchKernelGGL(k_undistort_cvt, grid, block, 0, s, d_raw, d_dst_slot, arena_img,
-                       reinterpret_cast<const short2*>(map1), map2, H, W);
+                       reinterpret_cast<const short2*>(map1), map2, H, W, PH);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -333,7 +349,7 @@ struct AArgs {
     const float2* tw_f; const float2* tw_i; const float2* tw_full;
     const float2* twI_f; const float2* twI_i;                // tables of PlanInv (spectrum-in kernels)
     // forward source
-    const float* src; size_t src_stride; const int* src_idx;
+    const float* src; size_t src_stride; const int* src_idx; int src_pitch;   // image planes: column pitch (>= rows, wrap rows behind)
     const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
     int H, W, SP; const uint32_t* polar_tab;                 // polar source: shifted planes, column pitch SP
     // spectrum side
@@ -374,24 +390,25 @@ __device__ __forceinline__ float2 load2(const float* p) {
 // the host, so the device does integer adds only.  nik_create() restricts the aspect ratio so that a rotation
 // about the centre keeps every source coordinate within one period: BORDER_WRAP is a single conditional add
 // (identical to cv::borderInterpolate there), and saturate_cast<short> can never clip.  Returns dst pixel (r, c).
-__device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H, int W, int ad, int bd, int X0, int Y0) {
+__device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H, int PH, int W, int ad, int bd, int X0, int Y0) {
     const int X = (X0 + ad) >> 5, Y = (Y0 + bd) >> 5;
     int xa = X >> 5, ya = Y >> 5;
     xa += (xa < 0) ? W : 0; xa -= (xa >= W) ? W : 0;
     ya += (ya < 0) ? H : 0; ya -= (ya >= H) ? H : 0;
-    const int xb = (xa + 1 == W) ? 0 : xa + 1, yb = (ya + 1 == H) ? 0 : ya + 1;
-    // the two taps of a column are adjacent in memory (rows are contiguous): one 8-byte load each, fixed up in the
-    // rare wrap case ya == H-1 (yb == 0)
-    const float* ca = img + (unsigned)(xa * H); const float* cb = img + (unsigned)(xb * H);
-    float2 va = load2(ca + ya), vb = load2(cb + ya);
-    if (yb == 0) { va.y = ca[0]; vb.y = cb[0]; }
+    const int xb = (xa + 1 == W) ? 0 : xa + 1;
+    // The two taps of a column are adjacent in memory (rows are contiguous) and every column carries a copy of its
+    // row 0 behind row H-1 (column pitch PH > H), so the vertical wrap needs no fix-up: one 8-byte load per column.
+    // Unsigned 32-bit element offsets (masked to 28 bits, a no-op for any real plane, so the byte offset provably
+    // fits 32 bits) from the wave-uniform image base: scalar-base + vector-offset loads, no per-lane 64-bit pointers.
+    const unsigned oa = (unsigned)(xa * PH + ya) & 0x0FFFFFFFu, ob = (unsigned)(xb * PH + ya) & 0x0FFFFFFFu;
+    const float2 va = load2(img + oa), vb = load2(img + ob);
     return bilerp(va.x, vb.x, va.y, vb.y, X & 31, Y & 31);
 }
 // polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven cv::remap sample from
 // the shifted, zero-bordered plane S (column pitch SP).  Table entry: offset(sx*SP+sy):22 | fx:5 | fy:5.
 __device__ __forceinline__ float polar_sample(const float* __restrict__ S, int SP, uint32_t t) {
-    const float* q = S + (t & 0x3FFFFF);
-    const float2 va = load2(q), vb = load2(q + SP);                 // (sx, sy..sy+1), (sx+1, sy..sy+1)
+    const unsigned o = t & 0x3FFFFF;
+    const float2 va = load2(S + o), vb = load2(S + (o + (unsigned)SP));   // (sx, sy..sy+1), (sx+1, sy..sy+1)
     return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
 }
 
@@ -519,7 +536,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
     if (j < D::MF) {
         if (SRC == SRC_PLANE) {
             const int pl = a.src_idx ? a.src_idx[item] : item;
-            const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.rows);
+            const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.src_pitch);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
         } else if (SRC == SRC_ROT) {
@@ -562,15 +579,16 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         const int ad = tab[c], bd = tab[a.cols + c];
         __syncthreads();
         if (j < D::MF) {
-            const float* img = a.src + (size_t)a.src_idx[item] * a.src_stride;
+            // (the slot index is the same for the whole workgroup: keep the image base in SGPRs)
+            const float* img = a.src + (size_t)__builtin_amdgcn_readfirstlane(a.src_idx[item]) * a.src_stride;
             const int2* X0 = reinterpret_cast<const int2*>(xy);
             const int2* Y0 = reinterpret_cast<const int2*>(xy + a.rows);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) {
                 const int m = j + q * D::MF;
                 const int2 xr = X0[m], yr = Y0[m];
-                vin[0][q] = make_float2(rot_sample(img, a.rows, a.cols, ad, bd, xr.x, yr.x),
-                                        rot_sample(img, a.rows, a.cols, ad, bd, xr.y, yr.y));
+                vin[0][q] = make_float2(rot_sample(img, a.rows, a.src_pitch, a.cols, ad, bd, xr.x, yr.x),
+                                        rot_sample(img, a.rows, a.src_pitch, a.cols, ad, bd, xr.y, yr.y));
                 // cap the number of gathers in flight (register pressure -> occupancy): no hoisting across groups
                 if ((q % KCC_GATHER_GROUP) == KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
             }
@@ -772,18 +790,18 @@ static AArgs base_args(PlaneGeom g, Tables t) {
         default: break;                   \
     }
 
-void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride,
+void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride, int src_pitch,
                         const int* src_idx, float2* dst, size_t dst_stride) {
     AArgs a = base_args(g, t);
-    a.src = src; a.src_stride = src_stride; a.src_idx = src_idx; a.spec = dst; a.spec_stride = dst_stride;
+    a.src = src; a.src_stride = src_stride; a.src_pitch = src_pitch; a.src_idx = src_idx; a.spec = dst; a.spec_stride = dst_stride;
 #define CALL(HH) launchA_fwd_t<HH, SRC_PLANE>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
-void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride,
+void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride, int img_pitch,
                       const int* img_slot, const int* rot_tab, const int* rot_index, float2* dst, size_t dst_stride) {
     AArgs a = base_args(g, t);
-    a.src = arena_img; a.src_stride = img_stride; a.src_idx = img_slot; a.rot_tab = rot_tab; a.rot_index = rot_index;
+    a.src = arena_img; a.src_stride = img_stride; a.src_pitch = img_pitch; a.src_idx = img_slot; a.rot_tab = rot_tab; a.rot_index = rot_index;
     a.spec = dst; a.spec_stride = dst_stride;
 #define CALL(HH) launchA_fwd_t<HH, SRC_ROT>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
@@ -1274,15 +1292,15 @@ void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W) 
     hipLaunchKernelGGL(k_make_shifted, dim3((H * W + 255) / 256), dim3(256), 0, s, p, S, H, W);
 }
 
-__global__ void k_dbg_rot(const float* __restrict__ img, const int* __restrict__ tab, float* __restrict__ out, int H, int W) {
+__global__ void k_dbg_rot(const float* __restrict__ img, const int* __restrict__ tab, float* __restrict__ out, int H, int W, int PH) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < H * W) {
         const int r = i % H, c = i / H;
-        out[i] = rot_sample(img, H, W, tab[c], tab[W + c], tab[2 * W + r], tab[2 * W + H + r]);
+        out[i] = rot_sample(img, H, PH, W, tab[c], tab[W + c], tab[2 * W + r], tab[2 * W + H + r]);
     }
 }
-void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W) {
-    hipLaunchKernelGGL(k_dbg_rot, dim3((H * W + 255) / 256), dim3(256), 0, s, img, rot_tab, out, H, W);
+void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W, int PH) {
+    hipLaunchKernelGGL(k_dbg_rot, dim3((H * W + 255) / 256), dim3(256), 0, s, img, rot_tab, out, H, W, PH);
 }
 __global__ void k_dbg_polar(const float* __restrict__ S, const uint32_t* __restrict__ tab, float* __restrict__ out,
                             int SP, int n) {
