@@ -96,7 +96,8 @@ struct nik_ctx {
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     float* d_scratch = nullptr;          // debug / import-export staging
-    uint32_t* polar_tab = nullptr;
+    uint32_t* polar_tab = nullptr;       // natural order [PC][PD] (debug tap)
+    uint32_t* polar_tab_sorted = nullptr; // hot path: per tile, sorted by source address, {entry, LDS destination} pairs
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
     // per-stage HIP-event profiler (nik_profile_enable / nik_profile_read)
@@ -206,6 +207,27 @@ int build_polar_table(nik_ctx* c) {
     }
     HIP_TRY(c, hipMalloc(&c->polar_tab, sizeof(uint32_t) * tab.size()));
     HIP_TRY(c, hipMemcpy(c->polar_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
+    // hot-path table: the samples of one kernel tile (`lines` radii x PD angles) sorted by source offset, so that the
+    // 64 lanes of a gather instruction share a few cache lines; y = float index of the sample in the tile's
+    // natural-order LDS buffer (line pitch `npitch` float2, angle phi at float 2*(phi/2) + (phi&1) = phi)
+    int lines = 0, npitch = 0;
+    polar_tile_layout(PD / 2, &lines, &npitch);
+    if (lines <= 0 || PC % lines) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "polar tile does not divide rotation_channel");
+    std::vector<uint32_t> sorted((size_t)PD * PC * 2);
+    std::vector<std::pair<uint32_t, uint32_t>> tile((size_t)lines * PD);
+    for (int t0 = 0; t0 < PC / lines; ++t0) {
+        for (int ln = 0; ln < lines; ++ln)
+            for (int phi = 0; phi < PD; ++phi)
+                tile[(size_t)ln * PD + phi] = { tab[(size_t)(t0 * lines + ln) * PD + phi], (uint32_t)(ln * npitch * 2 + phi) };
+        std::stable_sort(tile.begin(), tile.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
+            return (a.first & 0x3FFFFFu) < (b.first & 0x3FFFFFu); });
+        for (size_t i = 0; i < tile.size(); ++i) {
+            sorted[((size_t)t0 * tile.size() + i) * 2 + 0] = tile[i].first;
+            sorted[((size_t)t0 * tile.size() + i) * 2 + 1] = tile[i].second;
+        }
+    }
+    HIP_TRY(c, hipMalloc(&c->polar_tab_sorted, sizeof(uint32_t) * sorted.size()));
+    HIP_TRY(c, hipMemcpy(c->polar_tab_sorted, sorted.data(), sizeof(uint32_t) * sorted.size(), hipMemcpyHostToDevice));
     return NIK_OK;
 }
 
@@ -438,8 +460,8 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false)
     { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
       launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems); }
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
-    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 4.0 * c->PD * c->PC);
-      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab, L.tmpA, c->spec_max); }
+    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 8.0 * c->PD * c->PC);
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab_sorted, L.tmpA, c->spec_max); }
     if (defer_polar_B) return;
     { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
@@ -662,7 +684,7 @@ void nik_destroy(nik_ctx* c) {
     (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
     (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
     (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2);
-    (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->rot_tab);
+    (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->polar_tab_sorted); (void)hipFree(c->rot_tab);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     delete c;

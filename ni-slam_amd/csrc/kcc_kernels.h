@@ -89,6 +89,8 @@ void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride, int img_pitch,
                       const int* img_slot, const int* rot_tab, const int* rot_index,
                       float2* dst, size_t dst_stride);
+// tile geometry of the polar forward kernel: lines (radii) per workgroup and the LDS pitch (float2) of a natural line
+void polar_tile_layout(int hh, int* lines, int* npitch);
 // forward from polar(S), S = shifted zero-bordered planes [W+1][H+2] (gather fused into the load); g = polar geometry
 void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* S, size_t s_stride,
                         int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride);

@@ -546,21 +546,23 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         }
     }
     if (SRC == SRC_POLAR) {
-        // polar(fftshift(RemoveZeroComponent(p))): lanes = 16 radii x 4 angle pairs, i.e. a compact ~8 x 17 px patch
-        // of the source per wave-instruction (an arc of 64 angles would touch a different cache line per lane).
-        // Samples go to LDS in natural order, then every thread picks up its first-pass points.
+        // polar(fftshift(RemoveZeroComponent(p))).  The tile's samples (A_LX radii x all angles) are visited in the order
+        // of their SOURCE address (table sorted per tile on the host, each entry carrying its destination): the 64 lanes
+        // of a load then fall into a handful of 128-byte lines instead of ~30 -- the kernel is bound by L1 line
+        // look-ups, not by bytes.  Samples are scattered to LDS in natural order, then every thread picks up its
+        // first-pass points.
         const float* S = a.src + (size_t)item * a.src_stride;
-        const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab + (size_t)x0 * a.rows);
-        constexpr int TOT = A_LX * HH, ITERS = (TOT + C::NT - 1) / C::NT;
+        constexpr int TOT = A_LX * 2 * HH, ITERS = (TOT + C::NT - 1) / C::NT;
+        const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab) + (size_t)bx * TOT;
+        float* ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             const int idx = tid + it * C::NT;
             if (idx < TOT) {
-                const int ln = idx % A_LX, m = idx / A_LX;
-                const uint2 t = tab[(size_t)ln * HH + m];
-                lds[ln * C::NPITCH + m] = make_float2(polar_sample(S, a.SP, t.x), polar_sample(S, a.SP, t.y));
+                const uint2 t = tab[idx];                    // x: offset:22 | fx:5 | fy:5   y: LDS float index of the sample
+                ldsf[t.y] = polar_sample(S, a.SP, t.x);
             }
-            if ((it % KCC_GATHER_GROUP) == KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+            if ((it % (2 * KCC_GATHER_GROUP)) == 2 * KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (j < D::MF) {
@@ -753,6 +755,10 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     }
 }
 
+// tile geometry of the polar forward kernel for half length hh (the host sorts the gather table per tile)
+void polar_tile_layout(int hh, int* lines, int* npitch) {
+    *lines = hh >= 360 ? KCC_FLX360 : KCC_ALX; *npitch = hh + 1;
+}
 int argmax_blocks(PlaneGeom g) { return g.cols / a_lx(g.rows / 2); }
 
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
