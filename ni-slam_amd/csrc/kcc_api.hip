@@ -723,10 +723,13 @@ int nik_set_undistort(nik_ctx* c, const int16_t* map1, const uint16_t* map2) {
     (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2); c->ud_map1 = nullptr; c->ud_map2 = nullptr;
     if (!map1) return NIK_OK;
     const size_t n = c->img.real_elems;
-    HIP_TRY(c, hipMalloc(&c->ud_map1, n * 2 * sizeof(int16_t)));
-    HIP_TRY(c, hipMalloc(&c->ud_map2, n * sizeof(uint16_t)));
-    HIP_TRY(c, hipMemcpy(c->ud_map1, map1, n * 2 * sizeof(int16_t), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(c->ud_map2, map2, n * sizeof(uint16_t), hipMemcpyHostToDevice));
+    int16_t* m1 = nullptr; uint16_t* m2 = nullptr;             // installed only when both copies succeeded
+    hipError_t e = hipMalloc(&m1, n * 2 * sizeof(int16_t));
+    if (e == hipSuccess) e = hipMalloc(&m2, n * sizeof(uint16_t));
+    if (e == hipSuccess) e = hipMemcpy(m1, map1, n * 2 * sizeof(int16_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m2, map2, n * sizeof(uint16_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(m1); (void)hipFree(m2); return fail(c, NIK_ERR_HIP, "undistortion maps: %s", hipGetErrorString(e)); }
+    c->ud_map1 = m1; c->ud_map2 = m2;
     return NIK_OK;
 }
 

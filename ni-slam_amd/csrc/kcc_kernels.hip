@@ -576,7 +576,12 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         // stage (the taps) instead of two (table, then taps)
         const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
         int* xy = reinterpret_cast<int*>(lds);               // [X0 H | Y0 H], overwritten by the exchange afterwards
-        for (int i = tid; i < 2 * a.rows; i += C::NT) xy[i] = tab[2 * a.cols + i];
+        constexpr int NXY = 4 * HH;                          // 2 * rows; compile-time trip count: all loads issued together
+#pragma unroll
+        for (int it = 0; it < (NXY + C::NT - 1) / C::NT; ++it) {
+            const int i = tid + it * C::NT;
+            if (i < NXY) xy[i] = tab[2 * a.cols + i];
+        }
         const int c = x0 + line;
         const int ad = tab[c], bd = tab[a.cols + c];
         __syncthreads();

@@ -81,7 +81,8 @@ struct nik_stitcher {
                 const bool existing = it != cells.end();
                 if (!existing) {
                     CellBuf nb;
-                    if (hipMalloc(&nb.data, sizeof(int) * csz) != hipSuccess || hipMalloc(&nb.weight, sizeof(int) * csz) != hipSuccess) return NIK_ERR_HIP;
+                    if (hipMalloc(&nb.data, sizeof(int) * csz) != hipSuccess) return NIK_ERR_HIP;
+                    if (hipMalloc(&nb.weight, sizeof(int) * csz) != hipSuccess) { (void)hipFree(nb.data); return NIK_ERR_HIP; }
                     it = cells.emplace(key, nb).first;
                 }
                 launch_stitch_merge(stream, it->second.data, it->second.weight, tmp_data + k * csz, tmp_weight + k * csz, (int)csz, existing ? 1 : 0);
