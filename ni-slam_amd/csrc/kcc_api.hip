@@ -932,9 +932,12 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             // which needs sum|X|^2 of the finished spectrum before that kernel runs)
             fuse = (c->cfg.kernel != 1) && c->fuse_polar;
             enqueue_intermedium(c, L, m, fuse);
-            if ((rc = mark_written(c, L, li, curs + b, m))) return rc;
+            // (fused: the frames' polar spectra are completed by the pose's first kernel -- the write event other
+            // lanes wait on must come after it)
+            if (!fuse && (rc = mark_written(c, L, li, curs + b, m))) return rc;
         }
         if ((rc = enqueue_pose(c, L, m, not_large_rotation, fuse, win_centers ? win_radius : -1))) return rc;
+        if (fuse && (rc = mark_written(c, L, li, curs + b, m))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
         if ((rc = end_call(c, L))) return rc;

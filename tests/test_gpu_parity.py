@@ -350,8 +350,8 @@ def test_other_reference_geometries(H, W):
 def test_batch_shapes_and_stream_counts_agree():
     """results do not depend on batch size, chunking across streams, or the XCD-swizzle tail (n not a multiple of 8)"""
     geom = SMALL
-    n = 13
-    cf, orc, ocfg = _mk(geom, max_batch=16, max_frames=2 * n)
+    n = 45                                                 # >= 32: split across streams; 45 = 5 * 8 + 5 exercises the tails
+    cf, orc, ocfg = _mk(geom, max_batch=48, max_frames=2 * n)
     keys, curs, _ = _pairs(geom, n, 1500)
     import torch
     dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
@@ -365,9 +365,34 @@ def test_batch_shapes_and_stream_counts_agree():
         if base is None:
             base = got
         assert got == base, "streams=%d" % streams
-    for i in (0, 7, 12):                                   # one pair at a time gives the same bits
+    for i in (0, 7, 12, 44):                               # one pair at a time gives the same bits
         assert cf.pose(i, n + i, True)[2] == base[i]
     assert cf.pose_batch([], [], True) == []
+    cf.close()
+
+
+def test_cross_stream_hazards_on_frame_slots():
+    """a call that READS frame slots another stream is still WRITING (here: as keys, in reversed order, so every chunk
+    depends on the other stream's chunk) must wait for them -- including the polar spectra that the fused tracking path
+    completes in the pose's first kernel.  Queued back to back == executed with a full synchronisation in between."""
+    geom = SMALL
+    n = 64
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 2600)
+    import torch
+    dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
+    torch.cuda.synchronize()
+    key_slots, cur_slots = list(range(n)), list(range(n, 2 * n))
+    rev = cur_slots[::-1]
+    cf.set_streams(2)
+    cf.intermedium_batch_dev(dk.data_ptr(), n, key_slots)
+
+    def run(sync_between):
+        cf.track_batch_dev(dc.data_ptr(), key_slots, cur_slots, True, sync=sync_between)      # writes cur slots
+        return cf.pose_batch(rev, key_slots, True)                                             # reads them as keys
+    want = run(True)
+    for _ in range(5):
+        assert run(False) == want
     cf.close()
 
 
