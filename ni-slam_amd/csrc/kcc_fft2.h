@@ -114,7 +114,10 @@ template <> struct PlanFor<160> : Plan<160, 10, 16> {};
 template <> struct PlanFor<320> : Plan<320, 16, 20> {};
 template <> struct PlanFor<480> : Plan<480, KCC_P480> {};
 template <> struct PlanFor<640> : Plan<640, KCC_P640> {};
-template <> struct PlanFor<1280> : Plan<1280, 8, 10, 16> {};
+#ifndef KCC_P1280
+#define KCC_P1280 8, 10, 16
+#endif
+template <> struct PlanFor<1280> : Plan<1280, KCC_P1280> {};
 // reference configs/config_geekplus.yaml (448 x 448) and configs/config_HD.yaml (1600 x 1200)
 template <> struct PlanFor<224> : Plan<224, 14, 16> {};
 template <> struct PlanFor<448> : Plan<448, 7, 8, 8> {};

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build tuning variants of the library in parallel:  tools/buildvars.py name=-DFOO=1,-DBAR=2 name2=...
+"""Build tuning variants of the library in parallel:  tools/buildvars.py "name=-DFOO=1;-DBAR=2" name2=...
 Each variant becomes ni-slam_amd/libnislam_kcc_hip_<name>.so (benchmark them with tools/runvar.sh _<name> ...);
 the default library is rebuilt too.  Exits non-zero if any build fails."""
 import concurrent.futures as cf, importlib.util, os, sys
@@ -9,7 +9,7 @@ b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 V = {"": []}
 for a in sys.argv[1:]:
     k, _, d = a.partition("=")
-    V[k] = [x for x in d.split(",") if x]
+    V[k] = [x for x in d.split(";") if x]          # defs separated by ";" (macro values may contain commas)
 def go(kv):
     k, d = kv
     try:
