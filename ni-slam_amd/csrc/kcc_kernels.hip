@@ -911,6 +911,12 @@ struct BArgs {
 #ifndef KCC_BLK_BIG
 #define KCC_BLK_BIG 4
 #endif
+#ifndef KCC_BLK_HUGE
+#define KCC_BLK_HUGE 2
+#endif
+#ifndef KCC_BLK_HUGE2
+#define KCC_BLK_HUGE2 1
+#endif
 #ifndef KCC_BLK_BIG2
 #define KCC_BLK_BIG2 3
 #endif
@@ -919,7 +925,7 @@ template <int N, int MODE> struct BCfg {
     static constexpr int T = P::T;
     // exchange buffers per line: two for the modes that transform two planes at once, else one
     static constexpr int NV = (MODE == 2 || MODE == 3 || MODE == 4) ? 2 : 1;
-    static constexpr int LK = (T >= 128) ? 2 : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
+    static constexpr int LK = (T >= 128) ? (NV == 2 ? KCC_BLK_HUGE2 : KCC_BLK_HUGE) : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
                                                         : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
     static constexpr int NT = LK * T;
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
