@@ -545,7 +545,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
             // (polar: handled below with a patch-shaped lane mapping)
         }
     }
-    if (SRC == SRC_POLAR) {
+    if (SRC == SRC_POLAR && !(a.ablate & 1)) {
         // polar(fftshift(RemoveZeroComponent(p))).  The tile's samples (A_LX radii x all angles) are visited in the order
         // of their SOURCE address (table sorted per tile on the host, each entry carrying its destination): the 64 lanes
         // of a load then fall into a handful of 128-byte lines instead of ~30 -- the kernel is bound by L1 line
@@ -571,7 +571,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         }
         __syncthreads();                                     // natural buffer consumed before the exchange overwrites it
     }
-    if (SRC == SRC_ROT) {
+    if (SRC == SRC_ROT && !(a.ablate & 1)) {
         // stage this angle's row terms X0[r], Y0[r] (2H ints) in LDS: the gather then has ONE dependent global
         // stage (the taps) instead of two (table, then taps)
         const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
@@ -603,14 +603,14 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         __syncthreads();                                     // table consumed before the exchange buffer is written
     }
     float2* const ex[1] = { lds + line * C::EPITCH };
-    fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
+    if (!(a.ablate & 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
     __syncthreads();                                         // exchange buffer fully consumed
     if (j < D::ML) {
 #pragma unroll
         for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
     }
     __syncthreads();
-    a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+    if (!(a.ablate & 2)) a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
 }
 
 // row r within `radius` (cyclically) of the window centre, or -- rotation surfaces, whose source is point-symmetric --
