@@ -3,6 +3,7 @@
 #include <cstdio>
 typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float f2a __attribute__((ext_vector_type(2)));
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 // MODE 0: dword, random within `span` floats; 1: unaligned dwordx2 random; 2: aligned dwordx2 random (even index);
 // SPREAD: lanes of a wave fall into `lines` different 128-byte lines (rest of the address random inside the line)
 template <int MODE> __global__ void k(const float* __restrict__ src, float* out, int iters, unsigned span_mask, int lines) {
@@ -18,7 +19,8 @@ template <int MODE> __global__ void k(const float* __restrict__ src, float* out,
             idx &= span_mask;
             if (MODE == 0) acc += src[idx];
             else if (MODE == 1) { idx = idx > span_mask - 1 ? span_mask - 1 : idx; const f2u v = *reinterpret_cast<const f2u*>(src + idx); acc += v.x + v.y; }
-            else { idx &= ~1u; const f2a v = *reinterpret_cast<const f2a*>(src + idx); acc += v.x + v.y; }
+            else if (MODE == 2) { idx &= ~1u; const f2a v = *reinterpret_cast<const f2a*>(src + idx); acc += v.x + v.y; }
+            else { idx = idx > span_mask - 3 ? span_mask - 3 : idx; const f4u v = *reinterpret_cast<const f4u*>(src + idx); acc += v.x + v.y + v.z + v.w; }
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
@@ -37,8 +39,8 @@ template <int MODE> void run(const char* name, unsigned span_floats, int lines) 
 }
 int main() {
     for (int lines : {1, 2, 4, 8, 16, 32, 64}) {
-        run<0>("dword", 4096, lines); run<1>("dwordx2 align 4", 4096, lines); run<2>("dwordx2 align 8", 4096, lines);
+        run<0>("dword", 4096, lines); run<1>("dwordx2 align 4", 4096, lines); run<2>("dwordx2 align 8", 4096, lines); run<3>("dwordx4 align 4", 4096, lines);
     }
-    for (unsigned span : {1u << 14, 1u << 17, 1u << 20}) { run<1>("dwordx2 align 4", span, 64); }
+    for (unsigned span : {1u << 14, 1u << 17, 1u << 20}) { run<1>("dwordx2 align 4", span, 64); run<3>("dwordx4 align 4", span, 64); }
     return 0;
 }
