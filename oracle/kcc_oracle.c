@@ -45,6 +45,7 @@ struct ora_ctx {
     /* coarse-to-fine extension (BASELINE config 3, no reference counterpart): arg-max windows, [0] translation
        surface, [1] rotation surface; radius < 0 = off */
     int win_row[2], win_col[2], win_radius;
+    int force_rot_row, force_rot_col;   /* test hook: imposed rotation arg-max (row < 0: off) */
 };
 
 static inline ora_cf32 cmul(ora_cf32 a, ora_cf32 b) {
@@ -384,7 +385,7 @@ ora_ctx* ora_create(const ora_config* cfg, int image_height, int image_width) {
     ctx->cfg.height = image_height; ctx->cfg.width = image_width;
     ctx->H = image_height; ctx->W = image_width;
     ctx->PD = cfg->rotation_divisor; ctx->PC = cfg->rotation_channel;
-    ctx->win_radius = -1;
+    ctx->win_radius = -1; ctx->force_rot_row = -1; ctx->force_rot_col = -1;
     ctx->target_fft = get_target_fft(ctx, ctx->H, ctx->W);
     ctx->target_rotation_fft = get_target_fft(ctx, ctx->PD, ctx->PC);
     build_polar_maps(ctx);
@@ -580,7 +581,14 @@ int ora_compute_pose(ora_ctx* ctx, const ora_cf32* last_fft_result, const float*
     float* grot = (float*)malloc(sizeof(float) * (size_t)ctx->PD * ctx->PC);
     const float info_rots = ora_estimate_trans(ctx, last_fft_polar, fft_polar, 1, rots, &rr, &rc, grot, &err);   /* :103 */
     if (err) { free(grot); return -1; }
-    d.rot_row = rr; d.rot_col = rc; d.psr_rot = info_rots;
+    float info_rots_used = info_rots;
+    if (ctx->force_rot_row >= 0) {          /* test hook: another (near-tied) position of the same surface */
+        rr = ctx->force_rot_row; rc = ctx->force_rot_col;
+        rots[0] = -(rr - ctx->PD / 2); rots[1] = -(rc - ctx->PC / 2);
+        info_rots_used = ora_get_info(grot, (long)ctx->PD * ctx->PC, grot[(size_t)rc * ctx->PD + rr]);
+        d.rot_forced = 1;
+    }
+    d.rot_row = rr; d.rot_col = rc; d.psr_rot = info_rots_used;
     d.rot_peak = grot[(size_t)rc * ctx->PD + rr];
     d.rot_mirror = grot[(size_t)rc * ctx->PD + (rr + ctx->PD / 2) % ctx->PD];
     free(grot);
@@ -611,7 +619,7 @@ int ora_compute_pose(ora_ctx* ctx, const ora_cf32* last_fft_result, const float*
     const float theta = (float)(degree / 180 * M_PI);                                   /* :135 */
     info[0] = info_trans; pose[0] = trans[1];
     info[1] = info_trans; pose[1] = trans[0];
-    info[2] = info_rots;  pose[2] = theta;
+    info[2] = info_rots_used;  pose[2] = theta;
     d.degree_final = degree;
     /* :139-140 std::cout omitted (I/O) */
     if (faithful) {                                                                     /* :141 dead `rectify` */
@@ -775,6 +783,8 @@ void ora_remap_u8(const uint8_t* src, int width, int height, const int16_t* map1
 /* ======================================================================================================
  * Coarse-to-fine extension (BASELINE config 3; NO reference counterpart -- defined in SURVEY 8(d))
  * ====================================================================================================== */
+void ora_force_rotation(ora_ctx* ctx, int row, int col) { ctx->force_rot_row = row; ctx->force_rot_col = col; }
+
 void ora_set_window(ora_ctx* ctx, int rot_row, int rot_col, int trans_row, int trans_col, int radius) {
     ctx->win_row[1] = rot_row; ctx->win_col[1] = rot_col; ctx->win_row[0] = trans_row; ctx->win_col[0] = trans_col;
     ctx->win_radius = radius;                /* radius < 0: plain global arg-max again */

@@ -62,6 +62,7 @@ typedef struct {
     float degree_final;
     int   chosen;                  /* 0 = orig, 1 = veri (+180)                             */
     int   n_hyp;
+    int   rot_forced;              /* 1 if the rotation arg-max was imposed by ora_force_rotation (test hook)     */
 } ora_pose_debug;
 
 /* CorrelationFlow::CorrelationFlow  correlation_flow.cc:37-44 */
@@ -137,6 +138,9 @@ void ora_remap_u8(const uint8_t* src_rowmajor, int width, int height, const int1
 /* ---- coarse-to-fine extension (BASELINE config 3; no reference counterpart): restrict the arg-max of the next
  * ora_estimate_trans / ora_compute_pose calls to cyclic (2*radius+1)^2 windows (rotation surface: also around the
  * mirror row); radius < 0 switches it off.  2x2 box down-sampling of a u8 image. */
+/* test hook for near-ties of the rotation surface: the next ora_compute_pose calls take (row, col) as the rotation
+ * arg-max instead of searching (row < 0 switches it off); rot_peak then reports g at that position. */
+void ora_force_rotation(ora_ctx* ctx, int row, int col);
 void ora_set_window(ora_ctx* ctx, int rot_row, int rot_col, int trans_row, int trans_col, int radius);
 void ora_downsample_u8(const uint8_t* src_rowmajor, int width, int height, uint8_t* dst_rowmajor);
 

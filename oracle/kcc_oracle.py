@@ -30,7 +30,7 @@ class OraPoseDebug(C.Structure):
                 ("psr_rot", C.c_float), ("rot_peak", C.c_float), ("rot_mirror", C.c_float),
                 ("psr_trans", C.c_float * 2),
                 ("degree_used", C.c_float * 2), ("degree_final", C.c_float),
-                ("chosen", C.c_int), ("n_hyp", C.c_int)]
+                ("chosen", C.c_int), ("n_hyp", C.c_int), ("rot_forced", C.c_int)]
 
     def as_dict(self):
         return dict(rot_row=self.rot_row, rot_col=self.rot_col,
@@ -82,6 +82,7 @@ def lib():
         L.ora_undistort_maps.argtypes = [P, P, P, C.c_int, C.c_int, P, P]
         L.ora_remap_u8.argtypes = [P, C.c_int, C.c_int, P, P, P]
         L.ora_set_window.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.ora_force_rotation.argtypes = [P, C.c_int, C.c_int]
         L.ora_downsample_u8.argtypes = [P, C.c_int, C.c_int, P]
         _lib = L
     return _lib
@@ -111,6 +112,10 @@ class Oracle:
         if getattr(self, "_ctx", None):
             lib().ora_destroy(self._ctx)
             self._ctx = None
+
+    def force_rotation(self, row=-1, col=-1):
+        """test hook: impose the rotation arg-max of the following compute_pose calls (row < 0: off)"""
+        lib().ora_force_rotation(self._ctx, int(row), int(col))
 
     def set_window(self, rot_row, rot_col, trans_row, trans_col, radius):
         """coarse-to-fine extension: restrict both arg-max searches of the following calls (radius < 0: off)"""

@@ -1,0 +1,45 @@
+"""Large parity sweep at full size: N random 640x480 pairs (random shift up to +-48 px, rotation up to +-max_theta), GPU path
+through the C ABI against the CPU oracle (32 threads), both ComputePose modes.  TEST TOOL (uses the oracle as the checker).
+Prints one JSON line: pairs, exact rotation rows, accepted 180-degree ties, failures."""
+import json, os, sys, time
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+import numpy as np, torch, synth
+from kcc_helpers import check_pose_parity, nik
+from oracle import kcc_oracle as ko
+N = nik()
+H, W = 480, 640
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+max_theta = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+B = 128
+cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=B, max_frames=2 * B)
+ocfg = ko.default_config()
+ora = ko.Oracle(ocfg, H, W)
+out = {"pairs_per_mode": n, "max_theta_deg": max_theta}
+for small in (True, False):
+    exact = ties = near = fails = 0; worst_psr = 0.0; msgs = []
+    for b0 in range(0, n, B):
+        m = min(B, n - b0)
+        keys, curs, _ = synth.make_batch(m, H, W, seed0=50000 + b0 + (0 if small else 10 ** 6), max_shift=48, max_theta=max_theta)
+        dk = torch.from_numpy(keys).cuda(); dc = torch.from_numpy(curs).cuda(); torch.cuda.synchronize()
+        cf.intermedium_batch_dev(dk.data_ptr(), m, list(range(m)))
+        res = cf.track_batch_dev(dc.data_ptr(), list(range(m)), list(range(B, B + m)), small, sync=True)
+        poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, small, nthreads=32)
+        for i in range(m):
+            g = res[i].as_dict()
+
+            def rerun(row, col, i=i):          # the oracle with the rotation arg-max imposed at the GPU's position
+                kf, kp = ora.intermedium(ora.normalize_u8(keys[i]))
+                ci = ora.normalize_u8(curs[i]); _, cp = ora.intermedium(ci)
+                ora.force_rotation(row, col)
+                r = ora.compute_pose(kf, ci, kp, cp, small)
+                ora.force_rotation(-1, -1)
+                return r
+            ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], 720, rerun=rerun)
+            near += bool(ok and not ex and msg.startswith("near-tie"))
+            exact += bool(ok and ex); ties += bool(ok and not ex and not msg.startswith("near-tie")); fails += (not ok)
+            if ok and (ex or not msg.startswith("near-tie")):
+                worst_psr = max(worst_psr, max(abs(g["info"][k] - infos[i][k]) / abs(infos[i][k]) for k in (0, 2)))
+            if not ok and len(msgs) < 5: msgs.append("pair %d: %s" % (b0 + i, msg))
+    out["small_rot" if small else "large_rot"] = {"exact": exact, "mirror_tie_accepted": ties, "other_near_tie_verified": near, "failed": fails, "worst_psr_rel_err": round(worst_psr, 6), "first_failures": msgs}
+print(json.dumps(out))
