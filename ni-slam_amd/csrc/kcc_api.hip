@@ -86,6 +86,7 @@ struct nik_ctx {
     // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
     bool kzz_cache = false;
     int16_t* ud_map1 = nullptr; uint16_t* ud_map2 = nullptr;   // undistortion maps (nik_set_undistort); null = u8 inputs are already undistorted
+    bool zz_half = true;          // uncached Kzz: transform only the Hermitian half of its kernel plane ($NIK_ZZ_HALF=0: off)
     bool fuse_polar = true;       // tracking path: fuse the polar spectrum's last pass into the pose's first kernel ($NIK_FUSE_POLAR=0: off)
     float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
     std::vector<uint8_t> slot_kzz;       // 1: cache valid
@@ -494,9 +495,9 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
       launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
                        xstore, xstore_stride, xstore_slot); }
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
-      launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy); }
+      launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 0, 2, c->zz_half); }
     { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
-      launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max); }
+      launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, c->zz_half); }
     }
     const int nb = argmax_blocks(f.g);
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, win.row ? "argmax_win" : "argmax").c_str(), n * Cb(f));
@@ -663,6 +664,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->slot_kzz.assign(max_frames, 0);
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
     if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
+    if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 2;
     if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);

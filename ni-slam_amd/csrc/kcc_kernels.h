@@ -108,7 +108,7 @@ void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
 // energy 2 floats per item (gaussian: sum|X|^2, sum|Z|^2 over the half spectrum).
 void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, float2* buf, size_t item_stride,
                              size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy,
-                             int plane_first = 0, int n_planes = 2);
+                             int plane_first = 0, int n_planes = 2, bool zz_half = false);
 // inverse -> /(rows*cols) -> arg-max + moments partials
 void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                          Partial* partials, int partial_stride);
@@ -136,7 +136,7 @@ void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_
                       float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr);   // x_fwd: also keep X
 // G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
-                        size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride);
+                        size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride, bool zz_half = false);
 
 // ---- per-keyframe Kzz cache (SURVEY 8d "with Kzz cached"): the zz / xz halves of the kernel stage on their own
 // plane 0 := inv(|Z|^2)

@@ -355,6 +355,7 @@ struct AArgs {
     // spectrum side
     float2* spec; size_t spec_stride; size_t plane_stride;
     int plane_first, n_planes;                               // kernel_fwd: planes [plane_first, plane_first+n_planes) of each item
+    int zz_tiles;                                            // kernel_fwd over (zz, xz): > 0 = only this many column tiles of the zz plane (Hermitian half)
     // inverse outputs
     float* real_out; size_t real_stride;
     Partial* partials; int partial_stride;
@@ -638,9 +639,19 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     int bx, item2;
     constexpr bool KFWD = epi_is_kfwd(EPI);
     constexpr int KT = EPI == EPI_KFWD_POLY3 ? KT_POLY3 : (EPI == EPI_KFWD_POLYN ? KT_POLYN : KT_GAUSS);
-    xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2);
-    const int item = KFWD ? item2 / a.n_planes : item2;
-    const int plane = KFWD ? a.plane_first + item2 % a.n_planes : 0;
+    int item, plane;
+    if (KFWD && a.zz_tiles > 0) {
+        // Kzz's kernel plane is real and even (an autocorrelation), so its column W-c is the y-reversed column c and
+        // transforms to the conjugate: only the columns <= W/2 of plane 0 are processed (solve_inv mirrors the rest)
+        int t;
+        xcd_coords(a.zz_tiles + nbx, a.n_items, t, item);
+        plane = t < a.zz_tiles ? 0 : 1;
+        bx = plane ? t - a.zz_tiles : t;
+    } else {
+        xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2);
+        item = KFWD ? item2 / a.n_planes : item2;
+        plane = KFWD ? a.plane_first + item2 % a.n_planes : 0;
+    }
     const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
@@ -776,7 +787,9 @@ template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items,
 }
 template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
     a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
-    dim3 grid((a.cols / ICfg<HH>::LX) * n_items * nz), block(ICfg<HH>::NT);
+    const int nbx = a.cols / ICfg<HH>::LX;
+    if (a.zz_tiles > 0) a.zz_tiles = (a.cols / 2) / ICfg<HH>::LX + 1;          // columns [0, W/2] rounded up to whole tiles
+    dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + nbx) * n_items : nbx * n_items * nz), block(ICfg<HH>::NT);
     static const bool big_lds = (ICfg<HH>::BYTES > 65536) &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ICfg<HH>::BYTES) == hipSuccess);
     (void)big_lds;
@@ -844,10 +857,11 @@ void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
 }
 void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, float2* buf, size_t item_stride,
                              size_t plane_stride, KernelFn fn, unsigned* maxbuf, const float* energy,
-                             int plane_first, int n_planes) {
+                             int plane_first, int n_planes, bool zz_half) {
     AArgs a = base_args(g, t);
     a.spec = buf; a.spec_stride = item_stride; a.plane_stride = plane_stride; a.fn = fn; a.maxbuf = maxbuf; a.energy = energy;
     a.plane_first = plane_first; a.n_planes = n_planes;
+    a.zz_tiles = (zz_half && plane_first == 0 && n_planes == 2) ? 1 : 0;      // (the launcher turns the flag into the tile count)
     if (fn.type == 1) {
 #define CALL(HH) launchA_inv_t<HH, EPI_KFWD_GAUSS>(s, n_items, n_planes, a)
         DISPATCH_HALF(g.rows / 2, CALL)
@@ -897,6 +911,7 @@ struct BArgs {
     float2* dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; float lambda;
+    int zz_half;                                                  // SOLVE_INV: plane 0 holds only the columns <= N/2 (Hermitian)
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
     const float2* kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
 };
@@ -1077,7 +1092,22 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         // H = T/(Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l)
         float2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
         const float2* src = a.src + (size_t)item * a.src_stride + loff;
-        load_strided(vin[0], src, DF::MF, valid && j < DF::MF);
+        if (a.zz_half) {
+            // plane 0 (the Kzz kernel plane after its row pass) is Hermitian along x: element x > N/2 = conj(element N - x)
+            if (valid && j < DF::MF) {
+                const float2* row = a.src + (size_t)item * a.src_stride + (size_t)k * N;
+#pragma unroll
+                for (int q = 0; q < DF::RF; ++q) {
+                    const int x = (int)j + q * DF::MF;
+                    const float2 v = row[x <= N / 2 ? x : N - x];
+                    vin[0][q] = make_float2(v.x, x <= N / 2 ? v.y : -v.y);
+                }
+            } else {
+                zero_fill(vin[0]);
+            }
+        } else {
+            load_strided(vin[0], src, DF::MF, valid && j < DF::MF);
+        }
         load_strided(vin[1], src + a.in_plane_stride, DF::MF, valid && j < DF::MF);
         const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 0]));
         const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
@@ -1219,10 +1249,10 @@ void launch_store_mzz(hipStream_t s, int n, const unsigned* maxbuf, const int* s
     hipLaunchKernelGGL(k_store_mzz, dim3((n + 63) / 64), dim3(64), 0, s, n, maxbuf, slots, mzz);
 }
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
-                        size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride) {
+                        size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride, bool zz_half) {
     BArgs a = base_bargs(g, t);
     a.src = buf; a.src_stride = item_stride; a.in_plane_stride = plane_stride; a.maxbuf = maxbuf; a.lambda = lambda;
-    a.dst = out; a.dst_stride = out_stride;
+    a.dst = out; a.dst_stride = out_stride; a.zz_half = zz_half ? 1 : 0;
 #define CALL(N) launchB_t<N, B_SOLVE_INV>(s, n_items, a)
     DISPATCH_LINE(g.cols, CALL)
 #undef CALL

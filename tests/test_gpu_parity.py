@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import synth
-from kcc_helpers import FULL, SMALL, check_pose_parity, nik
+from kcc_helpers import FULL, SMALL, ang_diff, check_pose_parity, nik
 from oracle import kcc_oracle as ko
 
 pytestmark = pytest.mark.gpu
@@ -396,10 +396,18 @@ def test_cross_stream_hazards_on_frame_slots():
     cf.close()
 
 
-def _same_registration(a, b, rel=2e-5):
-    """identical arg-max indices / pose; PSR equal up to the rounding of differently fused FMAs"""
-    for k in ("pose", "rot_row", "rot_col", "trans_row", "trans_col", "chosen", "n_hyp", "degree_final"):
-        assert a[k] == b[k], (k, a[k], b[k])
+def _same_registration(a, b, rel=2e-5, PD=SMALL["PD"]):
+    """the same registration: identical pose and arg-max indices; PSR equal up to the rounding of differently fused
+    FMAs.  The two paths round the Kzz spectrum differently in the last bits, so the documented 180-degree mirror tie of
+    the rotation surface may resolve differently: the row then differs by PD/2, theta by a multiple of
+    2*pi and, with two hypotheses, their order swaps -- the chosen hypothesis is compared."""
+    assert a["pose"][:2] == b["pose"][:2] and ang_diff(a["pose"][2], b["pose"][2]) < 1e-6, (a["pose"], b["pose"])
+    assert a["rot_col"] == b["rot_col"] and (a["rot_row"] - b["rot_row"]) % (PD // 2) == 0, (a["rot_row"], b["rot_row"])
+    assert a["n_hyp"] == b["n_hyp"]
+    ca, cb = a["chosen"], b["chosen"]
+    if a["rot_row"] == b["rot_row"]:
+        assert ca == cb and a["trans_row"] == b["trans_row"] and a["trans_col"] == b["trans_col"] and a["degree_final"] == b["degree_final"]
+    assert (a["trans_row"][ca], a["trans_col"][ca]) == (b["trans_row"][cb], b["trans_col"][cb])
     for x, y in zip(a["info"], b["info"]):
         assert abs(x - y) <= rel * abs(y)
 
