@@ -133,7 +133,7 @@ void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
                       float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
-                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr);   // x_fwd: also keep X
+                      float2* xstore = nullptr, size_t xstore_stride = 0, const int* xstore_slot = nullptr, bool zz_half = false);   // x_fwd: also keep X
 // G = T/(Kzz/Mzz + lambda) * Kxz/Mxz with Kzz = fwd(buf plane 0), Kxz = fwd(buf plane 1); out = inv(G)
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride, bool zz_half = false);

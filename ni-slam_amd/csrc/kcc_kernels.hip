@@ -775,6 +775,8 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
 void polar_tile_layout(int hh, int* lines, int* npitch) {
     *lines = hh >= 360 ? KCC_FLX360 : KCC_ALX; *npitch = hh + 1;
 }
+// columns [0, W/2] rounded up to whole kernel_fwd tiles: what the Hermitian-half Kzz transform reads of the zz plane
+int zz_half_columns(PlaneGeom g) { const int lx = a_lx(g.rows / 2); return std::min(g.cols, ((g.cols / 2) / lx + 1) * lx); }
 int argmax_blocks(PlaneGeom g) { return g.cols / a_lx(g.rows / 2); }
 
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
@@ -911,7 +913,8 @@ struct BArgs {
     float2* dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; float lambda;
-    int zz_half;                                                  // SOLVE_INV: plane 0 holds only the columns <= N/2 (Hermitian)
+    int zz_half;                                                  // SOLVE_INV: plane 0 holds only the columns <= N/2 (Hermitian);
+                                                                  // (FWD_)MUL_INV: > 0 = number of zz-plane columns to store
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
     const float2* kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
 };
@@ -1031,7 +1034,13 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (!nofft) fft_chain<P, true, 2>(pr, o, j, ex2, a.tw_i);
         if (vst && j < DI::ML) {
             float2* d = a.dst + (size_t)item * a.dst_stride + loff;
-            store_strided(o[0], d, DI::ML);
+            if (a.zz_half > 0) {
+                // only the columns the Hermitian-half kernel_fwd reads (x < zz_half) of the zz plane are kept
+#pragma unroll
+                for (int q = 0; q < DI::RL; ++q) if ((int)j + q * DI::ML < a.zz_half) d[q * DI::ML] = o[0][q];
+            } else {
+                store_strided(o[0], d, DI::ML);
+            }
             store_strided(o[1], d + a.out_plane_stride, DI::ML);
         }
     } else if (MODE == B_ZZ_INV) {
@@ -1188,10 +1197,11 @@ void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_
                       const float2* xsrc, size_t x_stride, const int* x_idx,
                       const float2* zsrc, size_t z_stride, const int* z_idx,
                       float2* out, size_t item_stride, size_t plane_stride, unsigned* maxbuf_zero,
-                      float2* xstore, size_t xstore_stride, const int* xstore_slot) {
+                      float2* xstore, size_t xstore_stride, const int* xstore_slot, bool zz_half) {
     BArgs a = base_bargs(g, t);
     a.dst2 = x_fwd ? xstore : nullptr; a.dst2_stride = xstore_stride; a.dst2_slot = xstore_slot;
     a.maxbuf_zero = maxbuf_zero;
+    a.zz_half = zz_half ? zz_half_columns(g) : 0;
     a.src = xsrc; a.src_stride = x_stride; a.src_idx = x_idx; a.zsrc = zsrc; a.z_stride = z_stride; a.z_idx = z_idx;
     a.dst = out; a.dst_stride = item_stride; a.out_plane_stride = plane_stride;
     if (x_fwd) {
