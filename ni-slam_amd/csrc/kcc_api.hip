@@ -457,9 +457,9 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false)
       launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max); }
     { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
-                           L.gbuf, c->spec_max); }
+                           L.gbuf, c->spec_max, c->zz_half); }
     { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems); }
+      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, c->zz_half); }
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
     { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 8.0 * c->PD * c->PC);
       launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab_sorted, L.tmpA, c->spec_max); }

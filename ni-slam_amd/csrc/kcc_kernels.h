@@ -99,7 +99,7 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
                        float* dst, size_t dst_stride);
 // inverse, /(rows*cols), written fftshift-ed into the zero-bordered planes S (column pitch rows+2)
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride);
+                          float* S, size_t s_stride, bool even_half = false);
 // RemoveZeroComponent patch of the shifted planes (one workgroup per item)
 void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W);
 void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
@@ -126,7 +126,7 @@ void launch_B_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float
 // F = fwd(src) -> dst (slot), |F| -> inverse -> tmp
 void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                           float2* dstF_base, size_t dstF_stride, const int* dst_slot,
-                          float2* tmp, size_t tmp_stride);
+                          float2* tmp, size_t tmp_stride, bool even_half = false);
 // out planes (item_stride apart, plane_stride between zz and xz): inv(|Z|^2), inv(X conj Z).
 // X: x_fwd ? fwd(xsrc line) : xsrc line.  X plane index = x_idx ? x_idx[item] : item.
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,

@@ -647,6 +647,11 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
         xcd_coords(a.zz_tiles + nbx, a.n_items, t, item);
         plane = t < a.zz_tiles ? 0 : 1;
         bx = plane ? t - a.zz_tiles : t;
+    } else if (EPI == EPI_SHIFTED && a.zz_tiles > 0) {
+        // IFFT(|F|) is real and even as well: only the column tiles covering [0, W/2] are transformed, each column is
+        // also written to its mirror position (see the epilogue)
+        xcd_coords(a.zz_tiles, a.n_items, bx, item);
+        plane = 0;
     } else {
         xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2);
         item = KFWD ? item2 / a.n_planes : item2;
@@ -671,16 +676,28 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     if (EPI == EPI_SHIFTED) {
         // write fftshift(p) into the zero-bordered plane S (column pitch rows+2): out(r,c) at ((r+H/2)%H, (c+W/2)%W)
         // (circ_shift.h:238-244); RemoveZeroComponent's row/column are patched afterwards by k_fix_zero.
-        if (j < DI::ML) {
+        const int xcol = x0 + line;
+        const bool half = a.zz_tiles > 0;                    // columns > W/2 come from their mirrors
+        if (j < DI::ML && !(half && xcol > a.cols / 2)) {
             const int H = a.rows, W = a.cols, SP = H + 2;
-            int xs = x0 + line + W / 2; if (xs >= W) xs -= W;
+            int xs = xcol + W / 2; if (xs >= W) xs -= W;
             float* col = a.real_out + (size_t)item * a.real_stride + (size_t)xs * SP;
+            // p(r, c) = p(-r, -c): the same values are column W - c read backwards
+            const bool mirror = half && xcol != 0 && 2 * xcol != W;
+            int xm = W - xcol + W / 2; if (xm >= W) xm -= W;
+            float* colm = a.real_out + (size_t)item * a.real_stride + (size_t)xm * SP;
 #pragma unroll
             for (int q = 0; q < DI::RL; ++q) {
-                int ys = 2 * (j + q * DI::ML) + H / 2; if (ys >= H) ys -= H;
+                const int r = 2 * (j + q * DI::ML);
+                int ys = r + H / 2; if (ys >= H) ys -= H;
                 const float v0 = vout[0][q].x * rsize, v1 = vout[0][q].y * rsize;
                 if ((H / 2) & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
                 else *reinterpret_cast<float2*>(col + ys) = make_float2(v0, v1);
+                if (mirror) {
+                    int y0 = (r ? H - r : 0) + H / 2; if (y0 >= H) y0 -= H;          // row -r
+                    int y1 = (H - r - 1) + H / 2; if (y1 >= H) y1 -= H;              // row -(r + 1)
+                    colm[y0] = v0; colm[y1] = v1;
+                }
             }
         }
     } else if (EPI == EPI_REAL) {
@@ -791,7 +808,7 @@ template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items,
     a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
     const int nbx = a.cols / ICfg<HH>::LX;
     if (a.zz_tiles > 0) a.zz_tiles = (a.cols / 2) / ICfg<HH>::LX + 1;          // columns [0, W/2] rounded up to whole tiles
-    dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + nbx) * n_items : nbx * n_items * nz), block(ICfg<HH>::NT);
+    dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + (epi_is_kfwd(EPI) ? nbx : 0)) * n_items : nbx * n_items * nz), block(ICfg<HH>::NT);
     static const bool big_lds = (ICfg<HH>::BYTES > 65536) &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ICfg<HH>::BYTES) == hipSuccess);
     (void)big_lds;
@@ -850,9 +867,10 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
 #undef CALL
 }
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride) {
+                          float* S, size_t s_stride, bool even_half) {
     AArgs a = base_args(g, t);
     a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.real_out = S; a.real_stride = s_stride;
+    a.zz_tiles = even_half ? 1 : 0;                          // (the launcher turns the flag into the tile count)
 #define CALL(HH) launchA_inv_t<HH, EPI_SHIFTED>(s, n_items, 1, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
@@ -1007,7 +1025,15 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         for (int q = 0; q < DF::RL; ++q) f[0][q] = make_float2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
         __syncthreads();
         if (!nofft) fft_chain<P, true, 1>(f, o, j, ex1, a.tw_i);
-        if (vst && j < DI::ML) store_strided(o[0], a.dst2 + (size_t)item * a.dst2_stride + loff, DI::ML);
+        if (vst && j < DI::ML) {
+            float2* d2 = a.dst2 + (size_t)item * a.dst2_stride + loff;
+            if (a.zz_half > 0) {                              // only the columns the even-half inverse row pass reads
+#pragma unroll
+                for (int q = 0; q < DI::RL; ++q) if ((int)j + q * DI::ML < a.zz_half) d2[q * DI::ML] = o[0][q];
+            } else {
+                store_strided(o[0], d2, DI::ML);
+            }
+        }
     } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
         // xzf = xf * zf.conjugate() for (z,z) and (x,z)   (correlation_flow.cc:210-211,220-221)
         float2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
@@ -1185,10 +1211,10 @@ void launch_B_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float
 #undef CALL
 }
 void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float2* dstF_base, size_t dstF_stride, const int* dst_slot, float2* tmp, size_t tmp_stride) {
+                          float2* dstF_base, size_t dstF_stride, const int* dst_slot, float2* tmp, size_t tmp_stride, bool even_half) {
     BArgs a = base_bargs(g, t);
     a.src = src; a.src_stride = src_stride; a.dst = dstF_base; a.dst_stride = dstF_stride; a.dst_slot = dst_slot;
-    a.dst2 = tmp; a.dst2_stride = tmp_stride;
+    a.dst2 = tmp; a.dst2_stride = tmp_stride; a.zz_half = even_half ? zz_half_columns(g) : 0;
 #define CALL(N) launchB_t<N, B_FWD_ABS_INV>(s, n_items, a)
     DISPATCH_LINE(g.cols, CALL)
 #undef CALL
