@@ -73,8 +73,6 @@ def main():
     d_curs = torch.from_numpy(curs_b).to(dev)
     torch.cuda.synchronize()
 
-    if os.environ.get("NIK_ABLATE"):
-        N.load().nik_dbg_set_ablate(int(os.environ["NIK_ABLATE"]))
     cfg = N.default_config()
     cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
     key_slots = list(range(B))

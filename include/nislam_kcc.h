@@ -323,14 +323,26 @@ int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);
 
 /* CorrelationFlow::FFT / IFFT (correlation_flow.cc:53-77) on host arrays in the reference layouts.
  * which: 0 = image geometry (H x W), 1 = polar geometry (PD x PC). */
-/* performance ablation of the B-type kernels (results become garbage): 1 no loads, 2 no stores, 4 no FFT */
-int nik_dbg_set_ablate(int flags);
 int nik_dbg_fft (nik_ctx* ctx, int which, const float* x_colmajor, float* xf_out);
 int nik_dbg_ifft(nik_ctx* ctx, int which, const float* xf, float* x_out);
 /* RotateArray (utils.cc:154-161) of slot f's image by `degree2`/2 degrees (degree2 = 2*degree, integer). */
 int nik_dbg_rotate(nik_ctx* ctx, nik_frame f, int degree2, float* out_colmajor);
 /* polar(fftshift(RemoveZeroComponent(x))) (correlation_flow.cc:93-94) of a host H x W plane. */
 int nik_dbg_polar(nik_ctx* ctx, const float* x_colmajor, float* out_colmajor /*PD x PC*/);
+
+
+/* ---- host-side gather tables (tests only; no GPU needed) --------------------------------------
+ * The tables the two gather kernels consume, built exactly as nik_create builds them, so that CPU tests can replay
+ * the kernels' staging / sampling arithmetic against the oracle (tests/test_host_tables.py). */
+/* polar gather plan for geometry (H, W, PD, PC).  dims = {qs, nseg, tiles, lines, threads, rf, mf, lds_bytes}.
+ * chunks[n_chunks]: source offset of 16 consecutive floats;  seg_first[tiles*nseg+1];  pts[tiles*rf*lines*threads*4].
+ * The arrays are malloc'ed; release with nik_host_free. */
+int nik_host_polar_plan(int H, int W, int PD, int PC, int dims[8], uint32_t** chunks, int* n_chunks, int** seg_first, uint32_t** pts);
+void nik_host_free(void* p);
+/* cv::warpAffine fixed-point terms of RotateArray(image, degree): out[2W+2H] = adelta | bdelta | X0 | Y0 */
+int nik_host_rot_terms(int H, int W, float degree, int* out);
+/* LDS box geometry of the u8 de-rotation for image height H: geom = {band_rows, bands, box_rows, pitch, lds_bytes} */
+int nik_host_rot8_geom(int H, int geom[5]);
 
 #ifdef __cplusplus
 }

@@ -9,6 +9,7 @@
 // while the previous one is still running; results are finalised lazily (nik_synchronize or ring reuse).
 #include "../../include/nislam_kcc.h"
 #include "kcc_kernels.h"
+#include "kcc_tables.h"
 
 #include <algorithm>
 #include <cmath>
@@ -36,7 +37,8 @@ struct Family {                 // one plane geometry with its tables
 // index arrays of one call (each cap_items ints)
 enum { IX_KEY = 0, IX_CUR = 1, IX_DST = 2, IX_TIMG = 3, IX_TKEY = 4, IX_ROTIDX = 5,
        IX_WRR = 6, IX_WRC = 7, IX_WTR = 8, IX_WTC = 9,       // arg-max window centres (rotation / translation surface), host-written
-       IX_COUNT = 10 };
+       IX_CVT = 10,                                           // u8 frames to materialise as f32 planes (mixed u8 / f32 batches)
+       IX_COUNT = 11 };
 
 struct Call {                   // one in-flight call on a lane
     int* h_idx = nullptr;                                   // pinned staging, IX_COUNT * cap_items
@@ -61,6 +63,7 @@ struct Lane {
     float2* kbuf = nullptr;             // [cap_items][2][max spec]  (zz, xz planes)
     float2* gbuf = nullptr;             // [cap_items][max spec]
     float*  splane = nullptr;           // [cap_pairs][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
+    uint8_t* u8tmp = nullptr;           // [cap_pairs][H*W] undistorted frames (allocated by nik_set_undistort)
     Partial* partials = nullptr;
     unsigned* maxbuf = nullptr; float* energy = nullptr;
     SurfaceResult* rot_res = nullptr; SurfaceResult* trans_res = nullptr;
@@ -80,9 +83,13 @@ struct nik_ctx {
 
     Family img, pol;
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
-    float* arena_img = nullptr; float2* arena_F = nullptr; float2* arena_P = nullptr;
-    int img_pitch = 0; size_t img_stride = 0;   // image planes: column pitch >= H + 4 (rows H..H+3 repeat rows 0..3), elements per slot
+    // The image of a frame lives as u8 (row-major, what the u8 entry points receive) or as f32 (column-major, what the
+    // reference's ArrayXXf entry points hand over); slot_kind says which copies are valid.
+    uint8_t* arena_u8 = nullptr; float* arena_img = nullptr; float2* arena_F = nullptr; float2* arena_P = nullptr;
+    int u8_pitch = 0; size_t u8_stride = 0;     // u8 images: row pitch W + 16 (columns 0..15 repeated behind column W-1: BORDER_WRAP), bytes per slot
+    int img_pitch = 0; size_t img_stride = 0;   // f32 planes: column pitch >= H + 4 (rows H..H+3 repeat rows 0..3), elements per slot
     std::vector<uint8_t> slot_ready;     // bit0: image, bit1: spectra
+    std::vector<uint8_t> slot_kind;      // bit0: u8 image valid, bit1: f32 image valid
     // optional per-keyframe Kzz cache (SURVEY 8d "Kzz cached"): transformed kernel spectrum + max per slot and family
     bool kzz_cache = false;
     int16_t* ud_map1 = nullptr; uint16_t* ud_map2 = nullptr;   // undistortion maps (nik_set_undistort); null = u8 inputs are already undistorted
@@ -97,8 +104,8 @@ struct nik_ctx {
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     float* d_scratch = nullptr;          // debug / import-export staging
-    uint32_t* polar_tab = nullptr;       // natural order [PC][PD] (debug tap)
-    uint32_t* polar_tab_sorted = nullptr; // hot path: per tile, sorted by source address, {entry, LDS destination} pairs
+    PolarPlan polar{};                   // gather tables of the polar forward kernel (device pointers; kcc_tables.cpp)
+    int* rot_one = nullptr;              // one-angle de-rotation table (nik_dbg_rotate)
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
     // per-stage HIP-event profiler (nik_profile_enable / nik_profile_read)
@@ -176,88 +183,27 @@ int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     return NIK_OK;
 }
 
-inline int cv_round_f(float v) { return (int)lrintf(v); }
-
-// cv::warpPolar map (reference correlation_flow.cc:231-234) quantised as cv::remap does (1/32 px), stored
-// [PC][PD] so a polar line (fixed radius, all angles) is contiguous.  Entry: (sx*(H+2)+sy) | fx<<22 | fy<<27.
+// upload the polar gather plan (kcc_tables.cpp) for the forward kernel's tile geometry
 int build_polar_table(nik_ctx* c) {
-    const int PD = c->PD, PC = c->PC, H = c->H, W = c->W;
-    std::vector<uint32_t> tab((size_t)PD * PC);
-    const float cx = (float)W / 2, cy = (float)H / 2;
-    const double maxRadius = (double)std::min(H / 2, W / 2);
-    const double Kangle = (2.0 * 3.1415926535897932384626433832795) / PD;
-    const double Kmag = maxRadius / PC;
-    std::vector<float> rhos(PC);
-    for (int rho = 0; rho < PC; ++rho) rhos[rho] = (float)(rho * Kmag);
-    for (int phi = 0; phi < PD; ++phi) {
-        const double KKy = Kangle * phi;
-        const double cp = cos(KKy), sp = sin(KKy);
-        for (int rho = 0; rho < PC; ++rho) {
-            const float mx = (float)(rhos[rho] * cp + cx);
-            const float my = (float)(rhos[rho] * sp + cy);
-            const int qx = cv_round_f(mx * 32), qy = cv_round_f(my * 32);
-            const int sx = qx >> 5, sy = qy >> 5;
-            // all four taps must fall inside the zero-bordered plane S[W+1][H+2] (taps beyond the image read 0,
-            // exactly cv::remap's BORDER_CONSTANT path for a source that never leaves the image by more than 1 px)
-            if (sx < 0 || sy < 0 || sx + 1 > W || sy + 1 > H)
-                return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "polar map leaves the image by more than one pixel");
-            const uint32_t off = (uint32_t)sx * (uint32_t)(H + 2) + (uint32_t)sy;
-            if (off >= (1u << 22)) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "image too large for the packed polar table");
-            tab[(size_t)rho * PD + phi] = off | ((uint32_t)(qx & 31) << 22) | ((uint32_t)(qy & 31) << 27);
-        }
-    }
-    HIP_TRY(c, hipMalloc(&c->polar_tab, sizeof(uint32_t) * tab.size()));
-    HIP_TRY(c, hipMemcpy(c->polar_tab, tab.data(), sizeof(uint32_t) * tab.size(), hipMemcpyHostToDevice));
-    // hot-path table: the samples of one kernel tile (`lines` radii x PD angles) sorted by source offset, so that the
-    // 64 lanes of a gather instruction share a few cache lines; y = float index of the sample in the tile's
-    // natural-order LDS buffer (line pitch `npitch` float2, angle phi at float 2*(phi/2) + (phi&1) = phi)
-    int lines = 0, npitch = 0;
-    polar_tile_layout(PD / 2, &lines, &npitch);
-    if (lines <= 0 || PC % lines) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "polar tile does not divide rotation_channel");
-    std::vector<uint32_t> sorted((size_t)PD * PC * 2);
-    std::vector<std::pair<uint32_t, uint32_t>> tile((size_t)lines * PD);
-    for (int t0 = 0; t0 < PC / lines; ++t0) {
-        for (int ln = 0; ln < lines; ++ln)
-            for (int phi = 0; phi < PD; ++phi)
-                tile[(size_t)ln * PD + phi] = { tab[(size_t)(t0 * lines + ln) * PD + phi], (uint32_t)(ln * npitch * 2 + phi) };
-        std::stable_sort(tile.begin(), tile.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) {
-            return (a.first & 0x3FFFFFu) < (b.first & 0x3FFFFFu); });
-        for (size_t i = 0; i < tile.size(); ++i) {
-            sorted[((size_t)t0 * tile.size() + i) * 2 + 0] = tile[i].first;
-            sorted[((size_t)t0 * tile.size() + i) * 2 + 1] = tile[i].second;
-        }
-    }
-    HIP_TRY(c, hipMalloc(&c->polar_tab_sorted, sizeof(uint32_t) * sorted.size()));
-    HIP_TRY(c, hipMemcpy(c->polar_tab_sorted, sorted.data(), sizeof(uint32_t) * sorted.size(), hipMemcpyHostToDevice));
+    const FwdGeom fg = fwd_geom(c->PD / 2);
+    PolarPlanHost h; std::string err;
+    if (build_polar_plan(c->H, c->W, c->PD, c->PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err))
+        return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
+    uint32_t* d_chunks = nullptr; int* d_first = nullptr; uint4* d_pts = nullptr;
+    HIP_TRY(c, hipMalloc(&d_chunks, sizeof(uint32_t) * std::max<size_t>(h.chunks.size(), 1)));
+    c->polar.chunks = d_chunks;
+    HIP_TRY(c, hipMalloc(&d_first, sizeof(int) * h.seg_first.size()));
+    c->polar.seg_first = d_first;
+    HIP_TRY(c, hipMalloc(&d_pts, sizeof(uint32_t) * h.pts.size()));
+    c->polar.pts = d_pts;
+    HIP_TRY(c, hipMemcpy(d_chunks, h.chunks.data(), sizeof(uint32_t) * h.chunks.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_first, h.seg_first.data(), sizeof(int) * h.seg_first.size(), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_pts, h.pts.data(), sizeof(uint32_t) * h.pts.size(), hipMemcpyHostToDevice));
+    c->polar.qs = h.qs; c->polar.lds_bytes = h.lds_bytes;
     return NIK_OK;
 }
 
 double normalize_degree(double a) { return a - 360 * floor((a + 180) / 360); }     // utils.cc:173-175
-
-// Fixed-point terms of cv::warpAffine (WarpAffineInvoker, INTER_LINEAR) for RotateArray(image, degree_arg)
-// (utils.cc:154-161): the inverse of getRotationMatrix2D(center, angle, 1) in double, then
-//   adelta[c] = rint(M0*c*1024), bdelta[c] = rint(M3*c*1024), X0[r] = rint((M1*r+M2)*1024)+16, Y0[r] likewise.
-// Layout: [adelta W | bdelta W | X0 H | Y0 H].
-void rotation_terms(int H, int W, float degree_arg, int* out) {
-    const float cx = (float)(W / 2.), cy = (float)(H / 2.);
-    double angle = (double)degree_arg;
-    angle *= 3.1415926535897932384626433832795 / 180;
-    const double alpha = cos(angle) * 1.0, beta = sin(angle) * 1.0;
-    double M[6] = { alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy };
-    double D = M[0] * M[4] - M[1] * M[3];
-    D = D != 0 ? 1. / D : 0;
-    const double A11 = M[4] * D, A22 = M[0] * D;
-    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
-    const double b1 = -M[0] * M[2] - M[1] * M[5];
-    const double b2 = -M[3] * M[2] - M[4] * M[5];
-    M[2] = b1; M[5] = b2;
-    const int round_delta = 1024 / 32 / 2;
-    for (int c = 0; c < W; ++c) { out[c] = (int)lrint(M[0] * c * 1024); out[W + c] = (int)lrint(M[3] * c * 1024); }
-    for (int r = 0; r < H; ++r) {
-        out[2 * W + r] = (int)lrint((M[1] * r + M[2]) * 1024) + round_delta;
-        out[2 * W + H + r] = (int)lrint((M[4] * r + M[5]) * 1024) + round_delta;
-    }
-}
 
 // For every possible rotation arg-max row: the angles ComputePose feeds to RotateArray
 // (correlation_flow.cc:105-117).  variant 0: not_large_rotation; 1: `orig`; 2: `veri` (+180).
@@ -399,10 +345,38 @@ int depend_for_write(nik_ctx* c, Lane& L, int li, nik_frame f) {
     }
     return NIK_OK;
 }
-int mark_written(nik_ctx* c, Lane& L, int li, const int* slots, int n) {
+// kind: which image copy the call wrote (1 = u8, 2 = f32)
+int mark_written(nik_ctx* c, Lane& L, int li, const int* slots, int n, int kind) {
     L.write_seq += 1;
     HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
-    for (int i = 0; i < n; ++i) { c->slot_lane[slots[i]] = (int8_t)li; c->slot_seq[slots[i]] = L.write_seq; c->slot_ready[slots[i]] = 3; c->slot_kzz[slots[i]] = 0; }
+    for (int i = 0; i < n; ++i) {
+        c->slot_lane[slots[i]] = (int8_t)li; c->slot_seq[slots[i]] = L.write_seq; c->slot_ready[slots[i]] = 3; c->slot_kzz[slots[i]] = 0;
+        c->slot_kind[slots[i]] = (uint8_t)kind;
+    }
+    return NIK_OK;
+}
+
+// f32 column-major planes (/255) for those of the listed slots that only hold a u8 image, on lane L's stream
+int ensure_f32_images(nik_ctx* c, Lane& L, int li, int n, const nik_frame* slots) {
+    int k = 0;
+    for (int i = 0; i < n; ++i) {
+        const nik_frame f = slots[i];
+        if (c->slot_kind[f] & 2) continue;
+        bool dup = false;
+        for (int q = 0; q < k; ++q) dup |= hidx(L, IX_CVT)[q] == f;
+        if (!dup) hidx(L, IX_CVT)[k++] = f;
+    }
+    if (!k) return NIK_OK;
+    int rc = upload_idx(c, L, IX_CVT, k);
+    if (rc) return rc;
+    launch_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
+    // published as a slot write of this lane: other lanes order their reads of the new planes after it
+    L.write_seq += 1;
+    HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
+    for (int i = 0; i < k; ++i) {
+        const nik_frame f = hidx(L, IX_CVT)[i];
+        c->slot_kind[f] |= 2; c->slot_lane[f] = (int8_t)li; c->slot_seq[f] = L.write_seq;
+    }
     return NIK_OK;
 }
 
@@ -431,38 +405,41 @@ std::string kname(const char* base, int len, const char* mode) {
 inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
 inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
 
-// u8 frames -> normalised f32 planes in the arena slots IX_DST (ConvertMatToNormalizedArray, utils.cc:110-118); with
-// undistortion maps installed the input is the RAW camera frame and Camera::UndistortImage (camera.cc:92-93) is
-// fused into the conversion.
-void enqueue_u8_to_plane(nik_ctx* c, Lane& L, int m, const uint8_t* d_u8) {
-    if (c->ud_map1) {
-        Stage st(c, L, "k_undistort_cvt", m * (1.0 * c->img.real_elems + Rb(c->img)) + 6.0 * c->img.real_elems);
-        launch_undistort_cvt(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->ud_map1, c->ud_map2, c->H, c->W, c->img_pitch);
-    } else {
-        Stage st(c, L, "k_cvt_u8", m * (1.0 * c->img.real_elems + Rb(c->img)));
-        launch_cvt_u8(L.stream, m, d_u8, didx(L, IX_DST), c->arena_img, c->H, c->W, c->img_pitch);
-    }
-}
-
-// ComputeIntermedium (correlation_flow.cc:89-95) for n images already stored (f32, column-major) in the
-// arena slots listed in d_idx[IX_DST].
+// ComputeIntermedium (correlation_flow.cc:89-95) for n frames whose spectra go to the arena slots listed in d_idx[IX_DST].
+// d_u8 != null: the frames arrive as u8 row-major images (n contiguous); ConvertMatToNormalizedArray (utils.cc:110-118)
+//   is fused into the first FFT pass, which also files the images in the u8 frame store.  With undistortion maps
+//   installed d_u8 is the RAW camera frame and Camera::UndistortImage (camera.cc:92-93) runs first.
+// d_u8 == null: the frames are f32 column-major planes already stored in the arena slots (nik_intermedium_f32).
 // defer_polar_B: leave the polar spectrum's second (radius) pass to the caller -- the pose that follows fuses it into
 // its first kernel (fwd_mul_inv), which also writes the finished spectrum to the frame store.  L.tmpA then holds the
 // half-transformed polar spectra.
-void enqueue_intermedium(nik_ctx* c, Lane& L, int n, bool defer_polar_B = false) {
+void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool defer_polar_B = false) {
     hipStream_t s = L.stream;
     const int* dst = didx(L, IX_DST);
     const Family& I = c->img; const Family& P = c->pol;
-    { Stage st(c, L, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
-      launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max); }
+    if (d_u8) {
+        const double N = (double)c->img.real_elems;
+        if (c->ud_map1) {
+            Stage st(c, L, "k_undistort_u8", n * 2.0 * N + 6.0 * N);
+            launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W);
+            d_u8 = L.u8tmp;
+        }
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "u8").c_str(), n * (N + Cb(I)));
+        launch_A_fwd_u8(s, n, c->img.g, c->img.t, d_u8, c->img.real_elems, c->W, c->arena_u8, c->u8_stride, c->u8_pitch, dst, L.tmpA, c->spec_max);
+    } else {
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
+        launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max);
+    }
+    // IFFT(|F|) is real and even and the polar gather only reads the inscribed circle: columns |c| <= Rmax + 1 suffice
+    const int need = c->zz_half ? std::min(c->H / 2, c->W / 2) + 1 : 0;
     { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
-                           L.gbuf, c->spec_max, c->zz_half); }
+                           L.gbuf, c->spec_max, need); }
     { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, c->zz_half); }
+      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need); }
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
-    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)) + 8.0 * c->PD * c->PC);
-      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar_tab_sorted, L.tmpA, c->spec_max); }
+    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)));
+      launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max); }
     if (defer_polar_B) return;
     { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
@@ -510,7 +487,8 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
 // Leaves raw surface results in the call's h_rot / h_trans (valid after its `done` event).
 // polar_in_tmpA: the current frames' polar spectra are still half-transformed in L.tmpA (enqueue_intermedium with
 // defer_polar_B): the rotation stage finishes them, stores them in the frame store (slots IX_DST) and uses them.
-int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_in_tmpA = false, int win_radius = -1) {
+// img_u8: the current frames' images are read from the u8 frame store (else from the f32 planes).
+int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8, bool polar_in_tmpA = false, int win_radius = -1) {
     hipStream_t s = L.stream;
     const int n_hyp = not_large_rotation ? 1 : 2, nt = n * n_hyp;
     Window wrot, wtr;                       // coarse-to-fine: arg-max windows staged in IX_W* (win_radius >= 0)
@@ -528,9 +506,15 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool polar_
                      c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp, nullptr, 0, nullptr, wrot);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
-    { Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
-      launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_tab,
-                       didx(L, IX_ROTIDX), L.tmpA, c->spec_max); }
+    if (img_u8) {
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot8").c_str(), nt * (1.0 * c->img.real_elems + Cb(c->img)));
+        launch_A_fwd_rot8(s, nt, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_TIMG), c->rot_tab,
+                          didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
+    } else {
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
+        launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_tab,
+                         didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
+    }
     if (c->cfg.kernel == 1) {
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
         launch_B_fwd(s, nt, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
@@ -582,8 +566,9 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
     HIP_TRY(c, hipMalloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
     HIP_TRY(c, hipMalloc(&L.kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
     HIP_TRY(c, hipMalloc(&L.gbuf, sizeof(float2) * c->spec_max * c->max_items));
-    HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * c->s_elems * c->max_batch));
-    HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * c->s_elems * c->max_batch));      // zero borders are never overwritten
+    // (+16: the polar gather stages whole 16-float chunks, the last of which may start at the plane's last pixel)
+    HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
+    HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * (c->s_elems * c->max_batch + 16)));      // zero borders are never overwritten
     HIP_TRY(c, hipMalloc(&L.partials, sizeof(Partial) * c->partial_stride * c->max_items));
     HIP_TRY(c, hipMalloc(&L.maxbuf, sizeof(unsigned) * 2 * c->max_items));
     HIP_TRY(c, hipMalloc(&L.energy, sizeof(float) * 2 * c->max_items));
@@ -601,7 +586,7 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
 }
 void lane_free(Lane& L) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
-    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.partials);
+    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.partials);
     (void)hipFree(L.maxbuf); (void)hipFree(L.energy); (void)hipFree(L.rot_res); (void)hipFree(L.trans_res); (void)hipFree(L.d_idx);
     for (Call& call : L.ring) {
         if (call.h_idx) (void)hipHostFree(call.h_idx);
@@ -655,6 +640,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (((c->img_pitch / 32) & 1) == 0) c->img_pitch += 32;
     c->img_stride = (size_t)W * c->img_pitch;
     TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img_stride * max_frames));
+    c->u8_pitch = W + 16; c->u8_stride = (size_t)c->u8_pitch * H;
+    TRY_C(hipMalloc(&c->arena_u8, c->u8_stride * max_frames));
     TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_KzF, sizeof(float2) * c->img.spec_elems * max_frames));
@@ -665,6 +652,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
     if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
     if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
+    c->slot_kind.assign(max_frames, 0);
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 2;
     if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);
@@ -684,10 +672,11 @@ void nik_destroy(nik_ctx* c) {
     if (!c) return;
     for (Lane& L : c->lanes) lane_free(L);
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
-    (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
+    (void)hipFree(c->arena_u8); (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
     (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
     (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2);
-    (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(c->polar_tab); (void)hipFree(c->polar_tab_sorted); (void)hipFree(c->rot_tab);
+    (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(const_cast<uint32_t*>(c->polar.chunks)); (void)hipFree(const_cast<int*>(c->polar.seg_first));
+    (void)hipFree(const_cast<uint4*>(c->polar.pts)); (void)hipFree(c->rot_tab); (void)hipFree(c->rot_one);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     delete c;
@@ -732,6 +721,9 @@ int nik_set_undistort(nik_ctx* c, const int16_t* map1, const uint16_t* map2) {
     if (e == hipSuccess) e = hipMemcpy(m1, map1, n * 2 * sizeof(int16_t), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m2, map2, n * sizeof(uint16_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { (void)hipFree(m1); (void)hipFree(m2); return fail(c, NIK_ERR_HIP, "undistortion maps: %s", hipGetErrorString(e)); }
+    for (Lane& L : c->lanes)                                  // undistorted frames of one call (input of the first FFT pass)
+        if (!L.u8tmp && e == hipSuccess) e = hipMalloc(&L.u8tmp, n * (size_t)c->max_batch);
+    if (e != hipSuccess) { (void)hipFree(m1); (void)hipFree(m2); return fail(c, NIK_ERR_HIP, "undistortion staging: %s", hipGetErrorString(e)); }
     c->ud_map1 = m1; c->ud_map2 = m2;
     return NIK_OK;
 }
@@ -770,10 +762,9 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
         if ((rc = begin_call(c, L))) return rc;
         for (int i = 0; i < m; ++i) { if ((rc = depend_for_write(c, L, li, dst[b + i]))) return rc; hidx(L, IX_DST)[i] = dst[b + i]; }
         if ((rc = upload_idx(c, L, IX_DST, m))) return rc;
-        enqueue_u8_to_plane(c, L, m, d_gray + (size_t)b * c->img.real_elems);
-        enqueue_intermedium(c, L, m);
+        enqueue_intermedium(c, L, m, d_gray + (size_t)b * c->img.real_elems);
         HIP_TRY(c, hipGetLastError());
-        if ((rc = mark_written(c, L, li, dst + b, m)) || (rc = end_call(c, L))) return rc;
+        if ((rc = mark_written(c, L, li, dst + b, m, 1)) || (rc = end_call(c, L))) return rc;
     }
     return NIK_OK;
 }
@@ -802,9 +793,9 @@ int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {
     launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);
     hidx(L, IX_DST)[0] = dst;
     if ((rc = upload_idx(c, L, IX_DST, 1))) return rc;
-    enqueue_intermedium(c, L, 1);
+    enqueue_intermedium(c, L, 1, nullptr);
     HIP_TRY(c, hipGetLastError());
-    if ((rc = mark_written(c, L, 0, &dst, 1)) || (rc = end_call(c, L))) return rc;
+    if ((rc = mark_written(c, L, 0, &dst, 1, 2)) || (rc = end_call(c, L))) return rc;
     return drain_all(c);
 }
 
@@ -813,6 +804,10 @@ int nik_frame_export(nik_ctx* c, nik_frame f, float* image, float* fft_result, f
     int rc;
     if ((rc = nik_synchronize(c)) || (rc = check_slot(c, f, true))) return rc;
     hipStream_t s = c->lanes[0].stream;
+    if (image && !(c->slot_kind[f] & 2)) {                  // the frame arrived as u8: hand out ConvertMatToNormalizedArray of it
+        Lane& L = c->lanes[0];
+        if ((rc = begin_call(c, L)) || (rc = ensure_f32_images(c, L, 0, 1, &f)) || (rc = end_call(c, L)) || (rc = drain_all(c))) return rc;
+    }
     if (image) HIP_TRY(c, hipMemcpy2DAsync(image, sizeof(float) * c->H, c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch,
                                            sizeof(float) * c->H, c->W, hipMemcpyDeviceToHost, s));
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
@@ -839,7 +834,7 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
         HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
                                     sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, s));
         launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
-        c->slot_ready[f] |= 1;
+        c->slot_ready[f] |= 1; c->slot_kind[f] = 2;
     }
     if (fft_result) {
         HIP_TRY(c, hipMemcpyAsync(scratch, fft_result, sizeof(float2) * c->img.spec_elems, hipMemcpyHostToDevice, s));
@@ -927,19 +922,23 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             HIP_TRY(c, hipMemcpyAsync(L.d_idx + (size_t)L.cap_items * IX_WRR, L.cur->h_idx + (size_t)L.cap_items * IX_WRR,
                                       sizeof(int) * (size_t)L.cap_items * 4, hipMemcpyHostToDevice, L.stream));
         }
-        bool fuse = false;
+        bool fuse = false, img_u8 = true;
         if (d_gray) {
-            enqueue_u8_to_plane(c, L, m, d_gray + (size_t)b * c->img.real_elems);
             // the polar spectrum's last pass is fused into the pose's first kernel (not for the gaussian kernel,
             // which needs sum|X|^2 of the finished spectrum before that kernel runs)
             fuse = (c->cfg.kernel != 1) && c->fuse_polar;
-            enqueue_intermedium(c, L, m, fuse);
+            enqueue_intermedium(c, L, m, d_gray + (size_t)b * c->img.real_elems, fuse);
             // (fused: the frames' polar spectra are completed by the pose's first kernel -- the write event other
             // lanes wait on must come after it)
-            if (!fuse && (rc = mark_written(c, L, li, curs + b, m))) return rc;
+            if (!fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
+        } else {
+            // stored frames: de-rotate from the u8 frame store when every current frame has a u8 image; a batch that
+            // mixes in f32 frames (nik_intermedium_f32 / nik_frame_import) runs on f32 planes, materialised on demand
+            for (int i = b; i < e; ++i) if (!(c->slot_kind[curs[i]] & 1)) img_u8 = false;
+            if (!img_u8 && (rc = ensure_f32_images(c, L, li, m, curs + b))) return rc;
         }
-        if ((rc = enqueue_pose(c, L, m, not_large_rotation, fuse, win_centers ? win_radius : -1))) return rc;
-        if (fuse && (rc = mark_written(c, L, li, curs + b, m))) return rc;
+        if ((rc = enqueue_pose(c, L, m, not_large_rotation, img_u8, fuse, win_centers ? win_radius : -1))) return rc;
+        if (fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
         if ((rc = end_call(c, L))) return rc;
@@ -1148,8 +1147,6 @@ int nik_profile_read(nik_ctx* c, nik_stage_stat* out, int cap, int* n) {
 
 // ---- debug taps ---------------------------------------------------------------------------------
 
-int nik_dbg_set_ablate(int flags) { set_ablate(flags); return NIK_OK; }
-
 int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     if (!c || !x || !xf_out) return NIK_ERR_INVALID_ARG;
     int rc;
@@ -1186,23 +1183,30 @@ int nik_dbg_ifft(nik_ctx* c, int which, const float* xf, float* x_out) {
     return NIK_OK;
 }
 
+// RotateArray(frame image, degree2 / 2 degrees) through the hot gather (u8 or f32 source, whichever the slot holds)
 int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     if (!c || !out) return NIK_ERR_INVALID_ARG;
     int rc;
     if ((rc = nik_synchronize(c)) || (rc = check_slot(c, fr, false))) return rc;
     if (!(c->slot_ready[fr] & 1)) return fail(c, NIK_ERR_NOT_READY, "frame slot %d holds no image", fr);
     Lane& L = c->lanes[0]; hipStream_t s = L.stream;
-    std::vector<int> terms((size_t)2 * c->W + 2 * c->H);
+    std::vector<int> terms((size_t)2 * c->W + 2 * c->H + 2);
     rotation_terms(c->H, c->W, (float)degree2 * 0.5f, terms.data());             // RotateArray(image, degree2/2)
-    int* d_terms = reinterpret_cast<int*>(L.gbuf);
-    HIP_TRY(c, hipMemcpyAsync(d_terms, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
-    launch_dbg_rot(s, c->arena_img + (size_t)fr * c->img_stride, d_terms, c->d_scratch, c->H, c->W, c->img_pitch);
+    terms[terms.size() - 2] = fr; terms[terms.size() - 1] = 0;                   // [slot, table index] behind the terms
+    if (!c->rot_one) HIP_TRY(c, hipMalloc(&c->rot_one, sizeof(int) * terms.size()));
+    HIP_TRY(c, hipMemcpyAsync(c->rot_one, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
+    const int* d_slot = c->rot_one + terms.size() - 2; const int* d_index = d_slot + 1;
+    if (c->slot_kind[fr] & 1)
+        launch_A_fwd_rot8(s, 1, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, d_slot, c->rot_one, d_index, L.tmpA, c->spec_max, c->d_scratch);
+    else
+        launch_A_fwd_rot(s, 1, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, d_slot, c->rot_one, d_index, L.tmpA, c->spec_max, c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(out, c->d_scratch, sizeof(float) * c->img.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
     return NIK_OK;
 }
 
+// polar(fftshift(RemoveZeroComponent(x))) through the hot gather
 int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     if (!c || !x || !out) return NIK_ERR_INVALID_ARG;
     int rc;
@@ -1213,10 +1217,39 @@ int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
     launch_make_shifted(s, d_in, L.splane, c->H, c->W);
     launch_fix_zero(s, 1, L.splane, c->s_elems, c->H, c->W);
-    launch_dbg_polar(s, L.splane, c->polar_tab, d_out, c->H, c->W, c->PD, c->PC);
+    launch_A_fwd_polar(s, 1, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max, d_out);
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(float) * c->pol.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
+    return NIK_OK;
+}
+
+// ---- host-side gather tables (tests; no device needed) -------------------------------------------
+
+int nik_host_polar_plan(int H, int W, int PD, int PC, int dims[8], uint32_t** chunks, int* n_chunks, int** seg_first, uint32_t** pts) {
+    if (!dims || !chunks || !n_chunks || !seg_first || !pts) return NIK_ERR_INVALID_ARG;
+    if (!fft_half_supported(PD / 2)) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "FFT length not instantiated");
+    const FwdGeom fg = fwd_geom(PD / 2);
+    PolarPlanHost h; std::string err;
+    if (build_polar_plan(H, W, PD, PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err)) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
+    const int d[8] = { h.qs, h.nseg, h.tiles, h.lines, h.threads, h.rf, h.mf, (int)h.lds_bytes };
+    memcpy(dims, d, sizeof(d));
+    auto dup = [](const void* src, size_t bytes) { void* p = malloc(std::max<size_t>(bytes, 1)); if (p) memcpy(p, src, bytes); return p; };
+    *chunks = (uint32_t*)dup(h.chunks.data(), h.chunks.size() * 4); *n_chunks = (int)h.chunks.size();
+    *seg_first = (int*)dup(h.seg_first.data(), h.seg_first.size() * 4);
+    *pts = (uint32_t*)dup(h.pts.data(), h.pts.size() * 4);
+    return (*chunks && *seg_first && *pts) ? NIK_OK : NIK_ERR_INVALID_ARG;
+}
+void nik_host_free(void* p) { free(p); }
+int nik_host_rot_terms(int H, int W, float degree, int* out) {
+    if (!out || H <= 0 || W <= 0) return NIK_ERR_INVALID_ARG;
+    rotation_terms(H, W, degree, out);
+    return NIK_OK;
+}
+int nik_host_rot8_geom(int H, int geom[5]) {
+    if (!geom || !fft_half_supported(H / 2)) return NIK_ERR_INVALID_ARG;
+    const Rot8Geom r = rot8_geom(H / 2);
+    geom[0] = r.band_rows; geom[1] = r.bands; geom[2] = r.box_rows; geom[3] = r.pitch; geom[4] = r.lds_bytes;
     return NIK_OK;
 }
 

@@ -39,7 +39,6 @@ struct PlaneGeom {
     int hr;              // rows/2+1
 };
 
-void set_ablate(int flags);      // debug: 1 = no global loads, 2 = no global stores, 4 = no FFT chains (B-type kernels)
 bool fft_half_supported(int h);   // rows/2 instantiated?
 bool fft_line_supported(int n);   // cols instantiated?
 
@@ -59,16 +58,13 @@ struct PlanDesc { int n, np, r[3]; };
 PlanDesc plan_desc(int n);
 PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for half length n
 
-// ---- u8 -> f32 column-major (ConvertMatToNormalizedArray) ----
-// image planes have column pitch PH >= H + 4 (rows H..H+3 repeat rows 0..3: vertical wrap taps are contiguous)
-void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img,
+// ---- u8 frame-store image -> f32 column-major plane of the same slot (ConvertMatToNormalizedArray on demand) ----
+// f32 planes have column pitch PH >= H + 4 (rows H..H+3 repeat rows 0..3: vertical wrap taps are contiguous)
+void launch_cvt_u8(hipStream_t s, int n, const uint8_t* arena_u8, size_t u8_stride, int u8_pitch, const int* d_slot, float* arena_img,
                    int H, int W, int PH);
 void launch_img_wrap(hipStream_t s, float* img, int H, int W, int PH);     // refresh the wrap rows of one plane
-// Camera::UndistortImage (camera.cc:92-93): cv::remap with the fixed-point maps; u8 -> u8, and fused with the
-// u8 -> f32 column-major / 255 conversion (raw camera frame straight into the image arena)
+// Camera::UndistortImage (camera.cc:92-93): cv::remap with the fixed-point maps; u8 -> u8
 void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W);
-void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
-                          const int16_t* map1, const uint16_t* map2, int H, int W, int PH);
 
 // MapStitcher::AddImageToOccupancy (map_stitcher.cc:36-133): frame -> temporary cells, temporary cell -> map cell
 struct StitchPose { double r00, r01, r10, r11, x, y, cx, cy; };   // RotationMatrix2D(theta), image pose, image centre (W/2, H/2)
@@ -85,21 +81,45 @@ void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t np
 // forward from a real plane: src plane index = src_idx ? src_idx[item] : item
 void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* src, size_t src_stride, int src_pitch,
                         const int* src_idx, float2* dst, size_t dst_stride);
-// forward from the de-rotated image (RotateArray fused into the load)
+// forward from a u8 row-major image batch (ConvertMatToNormalizedArray fused into the load); every tile is also copied
+// into the u8 frame store (row pitch keep_pitch = W + 16; columns 0..15 repeated behind column W-1) when keep != null
+void launch_A_fwd_u8(hipStream_t s, int n_items, PlaneGeom g, Tables t, const uint8_t* src, size_t src_stride, int src_pitch,
+                     uint8_t* keep, size_t keep_stride, int keep_pitch, const int* keep_slot, float2* dst, size_t dst_stride);
+// forward from the de-rotated image (RotateArray fused into the load): f32 frames (column-major, wrap rows) ...
 void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride, int img_pitch,
                       const int* img_slot, const int* rot_tab, const int* rot_index,
-                      float2* dst, size_t dst_stride);
-// tile geometry of the polar forward kernel: lines (radii) per workgroup and the LDS pitch (float2) of a natural line
-void polar_tile_layout(int hh, int* lines, int* npitch);
+                      float2* dst, size_t dst_stride, float* dbg_plane = nullptr);
+// ... and u8 frames (row-major, wrap columns; source bands staged in LDS)
+void launch_A_fwd_rot8(hipStream_t s, int n_items, PlaneGeom g, Tables t, const uint8_t* arena_u8, size_t img_stride, int img_pitch,
+                       const int* img_slot, const int* rot_tab, const int* rot_index,
+                       float2* dst, size_t dst_stride, float* dbg_plane = nullptr);
+// geometry of the forward A kernels for half length hh (thread (line, j), j < mf, owns first-pass points j + q*mf, q < rf)
+// qs_opts: the segment sizes (first-pass points per thread staged at once) the polar kernel is instantiated for, largest first
+struct FwdGeom { int lines, threads, rf, mf; size_t lds_bytes; int qs_opts[3]; };
+FwdGeom fwd_geom(int hh);
+// LDS box geometry of the u8 de-rotation (a band of band_rows dst rows x 16 columns -> a box of box_rows x pitch bytes)
+struct Rot8Geom { int band_rows, bands, box_rows, pitch, lds_bytes; };
+Rot8Geom rot8_geom(int hh);
+// gather tables of the polar forward kernel (built on the host by build_polar_plan, kcc_tables.cpp)
+struct PolarPlan {
+    const uint32_t* chunks;      // staging chunks: source offset of 16 consecutive floats, per tile and segment
+    const int* seg_first;        // [tiles * nseg + 1] first descriptor of every (tile, segment)
+    const uint4* pts;            // [tiles][rf][lines*threads] entries of a thread's first-pass point (two samples):
+                                 //   x/z: LDS float offset of tap column sx :16 | fx:5 | fy:5,  y/w: LDS float offset of column sx+1
+    int qs;                      // first-pass points per thread and segment (one of FwdGeom::qs_opts)
+    size_t lds_bytes;            // staging bytes of the largest segment
+};
 // forward from polar(S), S = shifted zero-bordered planes [W+1][H+2] (gather fused into the load); g = polar geometry
 void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* S, size_t s_stride,
-                        int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride);
+                        int H, int W, const PolarPlan& pp, float2* dst, size_t dst_stride, float* dbg_plane = nullptr);
 // inverse to a real plane, scaled by 1/(rows*cols)
 void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                        float* dst, size_t dst_stride);
-// inverse, /(rows*cols), written fftshift-ed into the zero-bordered planes S (column pitch rows+2)
+// inverse, /(rows*cols), written fftshift-ed into the zero-bordered planes S (column pitch rows+2).
+// need_cols > 0: the plane is real and even (the zero-phase image) and only its columns |c| <= need_cols are consumed:
+// transform the column tiles covering [0, min(W/2, need_cols)] and write each column's mirror too; 0 = the whole plane
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride, bool even_half = false);
+                          float* S, size_t s_stride, int need_cols = 0);
 // RemoveZeroComponent patch of the shifted planes (one workgroup per item)
 void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W);
 void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
@@ -126,7 +146,7 @@ void launch_B_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float
 // F = fwd(src) -> dst (slot), |F| -> inverse -> tmp
 void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                           float2* dstF_base, size_t dstF_stride, const int* dst_slot,
-                          float2* tmp, size_t tmp_stride, bool even_half = false);
+                          float2* tmp, size_t tmp_stride, int need_cols = 0);   // need_cols: as launch_A_inv_shifted
 // out planes (item_stride apart, plane_stride between zz and xz): inv(|Z|^2), inv(X conj Z).
 // X: x_fwd ? fwd(xsrc line) : xsrc line.  X plane index = x_idx ? x_idx[item] : item.
 void launch_B_mul_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool x_fwd,
@@ -163,9 +183,6 @@ void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, 
 void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials,
                      SurfaceResult* out, int* rot_index, int n_hyp, int PD);
 
-// debug: the two gathers on their own (no FFT)
-void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W, int PH);
-void launch_dbg_polar(hipStream_t s, const float* S, const uint32_t* tab, float* out, int H, int W, int PD, int PC);
 
 // layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]
 void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols);

@@ -11,6 +11,8 @@
 #include "kcc_kernels.h"
 #include "kcc_fft2.h"
 
+#include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace kcc {
@@ -58,8 +60,16 @@ PlanDesc plan_desc(int n_) {
 #ifndef KCC_ALX
 #define KCC_ALX 16
 #endif
-int g_ablate = 0;            // debug ablation flags (nik_dbg_set_ablate): 1 no loads, 2 no stores, 4 no FFT, 8 exit at once (dispatch cost only)
-void set_ablate(int f) { g_ablate = f; }
+// Performance ablation (tuning builds only: -DKCC_ABLATE, tools/ablate.sh; results become garbage).  $NIK_ABLATE bits:
+// 1 no loads / gathers, 2 no stores, 4 no FFT, 8 exit at once (dispatch cost only), 16 no gather staging, 32 no gather sampling,
+// 64 no u8 frame-store copy.  The release library contains none of it (ABL() is a compile-time false).
+#ifdef KCC_ABLATE
+static int ablate_flags() { static const int f = getenv("NIK_ABLATE") ? atoi(getenv("NIK_ABLATE")) : 0; return f; }
+#define ABL(a, bit) (((a).ablate & (bit)) != 0)
+#else
+static int ablate_flags() { return 0; }
+#define ABL(a, bit) false
+#endif
 
 // lines per A-type workgroup: 16 float2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
 // use 8 so that twice as many independent workgroups fit in a CU's LDS (their phases overlap better)
@@ -140,22 +150,23 @@ __device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& i
 // ------------------------------------------------------------------------------------------------
 // u8 row-major -> f32 column-major, /255  (utils.cc:110-118)
 // ------------------------------------------------------------------------------------------------
-// 64 x 64 tile per workgroup: rows are read as uchar4 (64-byte row segments), transposed through LDS and written
-// as float4 along y (256-byte column segments).  Requires W % 4 == 0 and H % 4 == 0 (always true here).
+// u8 frame-store image -> f32 plane of the same slot (frames that arrived as u8 and are needed as f32: nik_frame_export,
+// batches mixing u8 and f32 frames).  64 x 64 tile per workgroup: rows are read as uchar4 (64-byte row segments),
+// transposed through LDS and written as float4 along y (256-byte column segments).  Requires W % 4 == 0 and H % 4 == 0.
 // Image planes are stored with column pitch PH >= H + 4: rows H..H+3 of a column repeat its rows 0..3, so a vertical
 // BORDER_WRAP tap pair (H-1, 0) is one contiguous 8-byte load (rot_sample).
-__global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
+__global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src, size_t src_stride, int src_pitch, const int* __restrict__ slot,
                                                 float* __restrict__ arena, int H, int W, int PH) {
     __shared__ float tile[64][65];                          // [x][y], odd pitch
     const int item = blockIdx.z, tid = threadIdx.x;
-    const uint8_t* in = src + (size_t)item * H * W;
-    float* out = arena + (size_t)dst_slot[item] * PH * W;
+    const uint8_t* in = src + (size_t)slot[item] * src_stride;
+    float* out = arena + (size_t)slot[item] * PH * W;
     const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int r = r0 + (tid >> 4) + 16 * it, c = c0 + 4 * (tid & 15);
         if (r < H && c < W) {
-            const uchar4 v = *reinterpret_cast<const uchar4*>(in + (size_t)r * W + c);
+            const uchar4 v = *reinterpret_cast<const uchar4*>(in + (size_t)r * src_pitch + c);
             const int y = (tid >> 4) + 16 * it, x = 4 * (tid & 15);
             tile[x + 0][y] = (float)v.x / 255.0f; tile[x + 1][y] = (float)v.y / 255.0f;
             tile[x + 2][y] = (float)v.z / 255.0f; tile[x + 3][y] = (float)v.w / 255.0f;
@@ -198,9 +209,10 @@ void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t np
     hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
 }
 
-void launch_cvt_u8(hipStream_t s, int n, const uint8_t* d_gray, const int* d_dst_slot, float* arena_img, int H, int W, int PH) {
+void launch_cvt_u8(hipStream_t s, int n, const uint8_t* arena_u8, size_t u8_stride, int u8_pitch, const int* d_slot, float* arena_img,
+                   int H, int W, int PH) {
     dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
-    hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, d_gray, d_dst_slot, arena_img, H, W, PH);
+    hipLaunchKernelGGL(k_cvt_u8, grid, block, 0, s, arena_u8, u8_stride, u8_pitch, d_slot, arena_img, H, W, PH);
 }
 // rows 0..3 of every column copied behind row H-1 (after a host import of a plane)
 __global__ void k_img_wrap(float* __restrict__ img, int H, int W, int PH) {
@@ -234,45 +246,9 @@ __global__ __launch_bounds__(256) void k_undistort_u8(const uint8_t* __restrict_
     const short2 m = map1[i];
     dst[(size_t)item * H * W + i] = (uint8_t)undistort_px(src + (size_t)item * H * W, H, W, make_int2(m.x, m.y), map2[i]);
 }
-// raw u8 row-major -> undistorted f32 column-major / 255: k_cvt_u8 with the remap fused into its load
-__global__ __launch_bounds__(256) void k_undistort_cvt(const uint8_t* __restrict__ src, const int* __restrict__ dst_slot,
-                                                       float* __restrict__ arena, const short2* __restrict__ map1,
-                                                       const uint16_t* __restrict__ map2, int H, int W, int PH) {
-    __shared__ float tile[64][65];                          // [x][y], odd pitch
-    const int item = blockIdx.z, tid = threadIdx.x;
-    const uint8_t* in = src + (size_t)item * H * W;
-    float* out = arena + (size_t)dst_slot[item] * PH * W;
-    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
-#pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int y = (tid >> 6) + 4 * it, x = tid & 63;    // one map row segment (64 entries) per wave: coalesced
-        const int r = r0 + y, c = c0 + x;
-        if (r < H && c < W) {
-            const short2 m = map1[(size_t)r * W + c];
-            tile[x][y] = (float)undistort_px(in, H, W, make_int2(m.x, m.y), map2[(size_t)r * W + c]) / 255.0f;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int x = (tid >> 4) + 16 * it, y = 4 * (tid & 15);
-        const int c = c0 + x, r = r0 + y;
-        if (c < W && r < H) {
-            const float4 v = make_float4(tile[x][y], tile[x][y + 1], tile[x][y + 2], tile[x][y + 3]);
-            *reinterpret_cast<float4*>(out + (size_t)c * PH + r) = v;
-            if (r == 0) *reinterpret_cast<float4*>(out + (size_t)c * PH + H) = v;      // wrap rows
-        }
-    }
-}
 void launch_undistort_u8(hipStream_t s, int n, const uint8_t* d_in, uint8_t* d_out, const int16_t* map1, const uint16_t* map2, int H, int W) {
     hipLaunchKernelGGL(k_undistort_u8, dim3((H * W + 255) / 256, n), dim3(256), 0, s, d_in, d_out,
                        reinterpret_cast<const short2*>(map1), map2, H, W);
-}
-void launch_undistort_cvt(hipStream_t s, int n, const uint8_t* d_raw, const int* d_dst_slot, float* arena_img,
-                          const int16_t* map1, const uint16_t* map2, int H, int W, int PH) {
-    dim3 grid((W + 63) / 64, (H + 63) / 64, n), block(256);
-    hipLaunchKernelGGL(k_undistort_cvt, grid, block, 0, s, d_raw, d_dst_slot, arena_img,
-                       reinterpret_cast<const short2*>(map1), map2, H, W, PH);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,7 +315,11 @@ void launch_stitch_merge(hipStream_t s, int* data, int* weight, const int* tmp_d
 // ------------------------------------------------------------------------------------------------
 // A-type kernels
 // ------------------------------------------------------------------------------------------------
-enum { SRC_PLANE = 0, SRC_ROT = 1, SRC_POLAR = 2 };
+enum { SRC_PLANE = 0, SRC_ROT = 1,          // f32 column-major planes (nik_intermedium_f32 / nik_frame_import frames)
+       SRC_U8 = 3,                          // u8 row-major image tile, /255 on the fly (ConvertMatToNormalizedArray fused)
+       SRC_ROT8 = 4,                        // RotateArray from the u8 frame store, source bands staged in LDS
+       SRC_POLAR_H = 5, SRC_POLAR_Q = 6, SRC_POLAR_T = 7 };  // polar gather from LDS-staged annulus segments holding rf/2 / 1 /
+                                                             // polar_qs_mid(rf) of a thread's first-pass points
 enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI_KFWD_GAUSS = 4, EPI_SHIFTED = 5,
        EPI_ARGMAX_WIN = 6 };   // arg-max restricted to a cyclic window per item (coarse-to-fine registration)
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
@@ -351,7 +331,13 @@ struct AArgs {
     // forward source
     const float* src; size_t src_stride; const int* src_idx; int src_pitch;   // image planes: column pitch (>= rows, wrap rows behind)
     const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
-    int H, W, SP; const uint32_t* polar_tab;                 // polar source: shifted planes, column pitch SP
+    int H, W, SP;                                            // polar source: shifted planes, column pitch SP
+    const uint32_t* polar_chunks; const int* polar_seg_first; const uint4* polar_pts;   // staging descriptors / per-thread sample entries
+    // u8 sources: SRC_U8 reads the batch input (row pitch src8_pitch) and copies its tile into the u8 frame store;
+    // SRC_ROT8 reads the u8 frame store (row pitch src8_pitch = W + 16, columns 0..15 repeated behind column W-1)
+    const uint8_t* src8; size_t src8_stride; int src8_pitch;
+    uint8_t* dst8; size_t dst8_stride; int dst8_pitch; const int* dst8_slot;
+    float* dbg_plane;                                        // debug tap: the gathered real plane of item 0 (column-major rows x cols)
     // spectrum side
     float2* spec; size_t spec_stride; size_t plane_stride;
     int plane_first, n_planes;                               // kernel_fwd: planes [plane_first, plane_first+n_planes) of each item
@@ -380,6 +366,11 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
     static constexpr int WPS = WPS_ > 8 ? 8 : (WPS_ < 1 ? 1 : WPS_);
 };
 
+template <int RR>
+__device__ __forceinline__ void zero_fill(float2 (&v)[RR]) {
+#pragma unroll
+    for (int q = 0; q < RR; ++q) v[q] = make_float2(0.f, 0.f);
+}
 // 8-byte load from a 4-byte aligned address (two vertically adjacent taps)
 __device__ __forceinline__ float2 load2(const float* p) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -405,19 +396,21 @@ __device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H
     const float2 va = load2(img + oa), vb = load2(img + ob);
     return bilerp(va.x, vb.x, va.y, vb.y, X & 31, Y & 31);
 }
-// polar(fftshift(RemoveZeroComponent(p))) (correlation_flow.cc:228-236): one table-driven cv::remap sample from
-// the shifted, zero-bordered plane S (column pitch SP).  Table entry: offset(sx*SP+sy):22 | fx:5 | fy:5.
-__device__ __forceinline__ float polar_sample(const float* __restrict__ S, int SP, uint32_t t) {
-    const unsigned o = t & 0x3FFFFF;
-    const float2 va = load2(S + o), vb = load2(S + (o + (unsigned)SP));   // (sx, sy..sy+1), (sx+1, sy..sy+1)
-    return bilerp(va.x, vb.x, va.y, vb.y, (t >> 22) & 31, t >> 27);
-}
-
 #ifndef KCC_FLX360
 #define KCC_FLX360 16
 #endif
 template <int HH> using FCfg = ACfg<HH, (HH >= 360 ? KCC_FLX360 : KCC_ALX), false>;            // forward (real -> spectrum) kernels
-template <int HH> using ICfg = ACfg<HH, a_lx(HH), true>;           // inverse (spectrum -> ...) kernels
+// inverse (spectrum -> ...) kernels; the read-only arg-max kernels pick their own tile width
+#ifndef KCC_ALX_AM
+#define KCC_ALX_AM KCC_ALX
+#endif
+#ifndef KCC_ALX_AM360
+#define KCC_ALX_AM360 KCC_ALX360
+#endif
+__host__ __device__ constexpr int inv_lx(int hh, int epi) {
+    return (epi == EPI_ARGMAX || epi == EPI_ARGMAX_WIN) ? (hh >= 360 ? KCC_ALX_AM360 : KCC_ALX_AM) : a_lx(hh);
+}
+template <int HH, int EPI> using ICfg = ACfg<HH, inv_lx(HH, EPI), true>;
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
@@ -520,59 +513,162 @@ __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict
 #ifndef KCC_ROT_WPS
 #define KCC_ROT_WPS 1
 #endif
+// (float)v / 255.0f for an 8-bit v, correctly rounded, in two FP operations: v*chi + RN(v*clo) with chi + clo = 1/255 to
+// 48 bits (exhaustively equal to the IEEE division for v = 0..255: tests/test_host_tables.py).  ConvertMatToNormalizedArray
+// (utils.cc:110-118) on the fly.
+__device__ __forceinline__ float unit_u8(unsigned v) {
+    const float x = (float)v;
+    return __builtin_fmaf(x, 0x1.010102p-8f, x * -0x1.fdfdfep-33f);
+}
+
+// SRC_ROT8 geometry: thread (line, j) of the first FFT pass owns dst rows 2(j + q MF), +1 for q < RF, i.e. q selects a band of
+// BR = 2 MF dst rows.  The source of a band x 16-column block is a rotated rectangle; its bounding box (any angle) is at most
+// BW x BH pixels (ceil(hypot(16, BR)) + alignment / tap margins; checked exhaustively over all 0.5-degree angles by
+// tests/test_host_tables.py).  Every band is staged into its own fixed-size LDS box (row pitch PITCH bytes).
+// middle segment size of the polar gather: the largest divisor of rf that is <= rf/4
+__host__ __device__ constexpr int polar_qs_mid(int rf) { int d = rf / 4 > 0 ? rf / 4 : 1; while (rf % d) --d; return d; }
+__host__ __device__ constexpr int isqrt_ceil(int v) { int r = 0; while (r * r < v) ++r; return r; }
+template <int HH> struct Rot8Cfg {
+    using D = Dir<typename FCfg<HH>::P, false>;
+    static constexpr int BR = 2 * D::MF, NB = D::RF;
+    static constexpr int DIAG = isqrt_ceil(FCfg<HH>::LX * FCfg<HH>::LX + BR * BR);
+    static constexpr int BH = DIAG + 2;                       // rows of a box
+    static constexpr int PITCH = ((DIAG + 5 + 15) / 16) * 16; // bytes per box row (box origin is aligned down to 4 pixels)
+    static constexpr int LPR = PITCH / 16;                    // 16-byte lanes per box row
+    static constexpr int BOX = BH * PITCH;
+    static constexpr int XY_OFF = ((NB * BOX + 15) / 16) * 16;        // [X0 2HH | Y0 2HH] ints
+    static constexpr int INFO_OFF = XY_OFF + 16 * HH;                 // int2 (ox, oy) per band
+    static constexpr int BYTES_ = INFO_OFF + 8 * NB;
+    static constexpr size_t BYTES = BYTES_ > (int)FCfg<HH>::BYTES ? (size_t)BYTES_ : FCfg<HH>::BYTES;
+};
+template <int HH, int SRC> __host__ __device__ constexpr size_t fwd_lds_bytes() {
+    return SRC == SRC_ROT8 ? Rot8Cfg<HH>::BYTES : FCfg<HH>::BYTES;
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
 template <int HH, int SRC>
-__global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<HH>::WPS)) void kA_fwd(AArgs a) {
+__global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) ? KCC_ROT_WPS : FCfg<HH>::WPS)) void kA_fwd(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);   // lines are wave-local: no workgroup barriers inside the chain
+    constexpr bool POLAR = (SRC == SRC_POLAR_H || SRC == SRC_POLAR_Q || SRC == SRC_POLAR_T);
     float2* lds = reinterpret_cast<float2*>(smem);
-    if (a.ablate & 8) return;
+    if (ABL(a, 8)) return;
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
     int bx, item;
     constexpr int A_LX = C::LX;
-    xcd_coords(a.cols / A_LX, a.n_items, bx, item);
+    if (POLAR) {
+        // tile-major order, outermost (most expensive) ring first: the workgroups running at any time share one tile's
+        // gather tables (L2-resident), and every item's annulus is read exactly once
+        const int nbx = a.cols / A_LX;
+        bx = nbx - 1 - (int)(blockIdx.x / (unsigned)a.n_items); item = (int)(blockIdx.x % (unsigned)a.n_items);
+    } else {
+        xcd_coords(a.cols / A_LX, a.n_items, bx, item);
+    }
     const int x0 = bx * A_LX;
 
     float2 vin[1][D::RF], vout[1][D::RL];
-    if (j < D::MF) {
-        if (SRC == SRC_PLANE) {
+#ifdef KCC_ABLATE
+    zero_fill(vin[0]);
+#endif
+    if (SRC == SRC_PLANE) {
+        if (j < D::MF) {
             const int pl = a.src_idx ? a.src_idx[item] : item;
             const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.src_pitch);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
-        } else if (SRC == SRC_ROT) {
-            // (handled below: needs the whole workgroup for the LDS staging of the angle's X0/Y0 terms)
-        } else {
-            // (polar: handled below with a patch-shaped lane mapping)
         }
     }
-    if (SRC == SRC_POLAR && !(a.ablate & 1)) {
-        // polar(fftshift(RemoveZeroComponent(p))).  The tile's samples (A_LX radii x all angles) are visited in the order
-        // of their SOURCE address (table sorted per tile on the host, each entry carrying its destination): the 64 lanes
-        // of a load then fall into a handful of 128-byte lines instead of ~30 -- the kernel is bound by L1 line
-        // look-ups, not by bytes.  Samples are scattered to LDS in natural order, then every thread picks up its
-        // first-pass points.
-        const float* S = a.src + (size_t)item * a.src_stride;
-        constexpr int TOT = A_LX * 2 * HH, ITERS = (TOT + C::NT - 1) / C::NT;
-        const uint2* tab = reinterpret_cast<const uint2*>(a.polar_tab) + (size_t)bx * TOT;
-        float* ldsf = reinterpret_cast<float*>(lds);
+    if (SRC == SRC_U8 && !ABL(a, 1)) {
+        // ConvertMatToNormalizedArray (utils.cc:110-118) fused into the first FFT pass: the tile's 16 image columns are
+        // 16 bytes of every image row.  Rows are staged in LDS ([row][16 bytes]) and copied into the u8 frame store
+        // (the de-rotation of ComputePose reads the image from there); a thread then picks up its points as bytes.
+        const uint8_t* in = a.src8 + (size_t)item * a.src8_stride + x0;
+        uint8_t* keep = a.dst8 ? a.dst8 + (size_t)a.dst8_slot[item] * a.dst8_stride + x0 : nullptr;
+        uint4* st = reinterpret_cast<uint4*>(smem);
+        constexpr int ROWS = 2 * HH;
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int idx = tid + it * C::NT;
-            if (idx < TOT) {
-                const uint2 t = tab[idx];                    // x: offset:22 | fx:5 | fy:5   y: LDS float index of the sample
-                ldsf[t.y] = polar_sample(S, a.SP, t.x);
+        for (int it = 0; it < (ROWS + C::NT - 1) / C::NT; ++it) {
+            const int r = tid + it * C::NT;
+            if (r < ROWS) {
+                const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)r * a.src8_pitch);
+                st[r] = v;
+                if (keep && !ABL(a, 64)) {
+                    *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch) = v;
+                    if (bx == 0) *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + a.cols) = v;   // wrap columns
+                }
             }
-            if ((it % (2 * KCC_GATHER_GROUP)) == 2 * KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         if (j < D::MF) {
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(smem) + line;
 #pragma unroll
-            for (int q = 0; q < D::RF; ++q) vin[0][q] = lds[line * C::NPITCH + j + q * D::MF];
+            for (int q = 0; q < D::RF; ++q) {
+                const int m = j + q * D::MF;
+                vin[0][q] = make_float2(unit_u8(sb[32 * m]), unit_u8(sb[32 * m + 16]));
+            }
         }
-        __syncthreads();                                     // natural buffer consumed before the exchange overwrites it
+        __syncthreads();                                     // staged rows consumed before the exchange overwrites them
     }
-    if (SRC == SRC_ROT && !(a.ablate & 1)) {
+    if (POLAR && !ABL(a, 1)) {
+        // polar(fftshift(RemoveZeroComponent(p)))  (correlation_flow.cc:228-236).  The source pixels of the tile's
+        // samples (A_LX radii x all angles = an annulus) are staged in LDS one angular segment at a time: the host lists,
+        // per tile and segment, the runs of source pixels as chunks of 16 consecutive floats (column-major S, so a
+        // chunk is a piece of one source column); chunk c lands in LDS floats [16c, 16c+16) via LDS-DMA (four lanes x
+        // 16 bytes).  Every thread then bilinearly samples its own first-pass
+        // points straight into registers from entries that hold the LDS positions of the two tap columns.
+        constexpr int QS = SRC == SRC_POLAR_H ? D::RF / 2 : (SRC == SRC_POLAR_T ? polar_qs_mid(D::RF) : 1), NSEG = D::RF / QS;
+        static_assert(NSEG * QS == D::RF, "segments must tile the first-pass points");
+        const float* S = a.src + (size_t)item * a.src_stride;
+        float* ldsf = reinterpret_cast<float*>(smem);
+        const uint4* pts = a.polar_pts + (size_t)bx * D::RF * C::NT + tid;
+        const int l4 = tid & 3;
+#pragma unroll
+        for (int seg = 0; seg < NSEG; ++seg) {
+            if (seg) __syncthreads();                        // previous segment consumed
+            const int c0 = a.polar_seg_first[bx * NSEG + seg], nch = a.polar_seg_first[bx * NSEG + seg + 1] - c0;
+            const uint32_t* ch = a.polar_chunks + c0;
+            // (chunk offsets first, LDS-DMA afterwards: a wait for an offset would also wait for every DMA issued before it)
+            constexpr int G = 8, PER = C::NT / 4;            // chunks per pass of the workgroup; G passes per group
+            if (!ABL(a, 16))
+            for (int cb = 0; cb < nch; cb += G * PER) {
+                unsigned off[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { const int c = cb + g * PER + (tid >> 2); off[g] = (c < nch ? ch[c] : 0u) + 4 * l4; }
+#pragma unroll
+                for (int g = 0; g < G; ++g) asm volatile("" : "+v"(off[g]));     // the offsets are consumed (waited for) HERE
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    const int c = cb + g * PER + (tid >> 2);
+                    if (c < nch)
+                        __builtin_amdgcn_global_load_lds((glb_void*)(S + off[g]), (lds_void*)(ldsf + (cb + g * PER) * 16 + (tid & ~63) * 4), 16, 0, 0);
+                }
+            }
+            uint4 e[QS];
+            if (j < D::MF) {
+#pragma unroll
+                for (int qq = 0; qq < QS; ++qq) e[qq] = pts[(size_t)(seg * QS + qq) * C::NT];
+            }
+            __syncthreads();
+            if (j < D::MF && !ABL(a, 32)) {
+#pragma unroll
+                for (int qq = 0; qq < QS; ++qq) {
+                    float r[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const unsigned lo = h ? e[qq].z : e[qq].x, hi = h ? e[qq].w : e[qq].y;
+                        const float2 va = load2(ldsf + (lo & 0xFFFFu)), vb = load2(ldsf + hi);   // (sx; sy, sy+1), (sx+1; sy, sy+1)
+                        r[h] = bilerp(va.x, vb.x, va.y, vb.y, (lo >> 16) & 31, (lo >> 21) & 31);
+                    }
+                    vin[0][seg * QS + qq] = make_float2(r[0], r[1]);
+                }
+            }
+        }
+        __syncthreads();                                     // staged pixels consumed before the exchange overwrites them
+    }
+    if (SRC == SRC_ROT && !ABL(a, 1)) {
         // stage this angle's row terms X0[r], Y0[r] (2H ints) in LDS: the gather then has ONE dependent global
         // stage (the taps) instead of two (table, then taps)
         const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * a.cols + 2 * a.rows);
@@ -603,15 +699,92 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (SRC == SRC_ROT ? KCC_ROT_WPS : FCfg<
         }
         __syncthreads();                                     // table consumed before the exchange buffer is written
     }
+    if (SRC == SRC_ROT8 && !ABL(a, 1)) {
+        // RotateArray (utils.cc:154-161) = cv::warpAffine(INTER_LINEAR, BORDER_WRAP) from the u8 frame store.  Band q of
+        // the tile (dst rows [q BR, (q+1) BR) x 16 dst columns) reads a rotated rectangle of the source; its bounding box
+        // is staged in LDS (row-major bytes, BORDER_WRAP applied while staging: rows modulo H, columns through the 16
+        // repeated columns behind every stored row), so the taps are plain LDS byte reads at un-wrapped coordinates.
+        using R = Rot8Cfg<HH>;
+        const int rows = 2 * HH, W = a.cols;
+        const int* tab = a.rot_tab + (size_t)a.rot_index[item] * (2 * W + 2 * rows);
+        int* xy = reinterpret_cast<int*>(smem + R::XY_OFF);
+        int2* info = reinterpret_cast<int2*>(smem + R::INFO_OFF);
+        constexpr int NXY = 4 * HH;
+#pragma unroll
+        for (int it = 0; it < (NXY + C::NT - 1) / C::NT; ++it) {
+            const int i = tid + it * C::NT;
+            if (i < NXY) xy[i] = tab[2 * W + i];
+        }
+        const int c = x0 + line;
+        const int ad = tab[c], bd = tab[W + c];
+        if (tid < R::NB) {
+            // box origin of band `tid`: the fixed-point coordinate terms are monotone in r and in c, so the extremes sit
+            // at the corners of the block
+            const int r0 = tid * R::BR, r1 = r0 + R::BR - 1;
+            const int ax0 = tab[x0], ax1 = tab[x0 + A_LX - 1], ay0 = tab[W + x0], ay1 = tab[W + x0 + A_LX - 1];
+            const int X0a = tab[2 * W + r0], X0b = tab[2 * W + r1], Y0a = tab[2 * W + rows + r0], Y0b = tab[2 * W + rows + r1];
+            const int xmin = (min(X0a, X0b) + min(ax0, ax1)) >> 10, ymin = (min(Y0a, Y0b) + min(ay0, ay1)) >> 10;
+            info[tid] = make_int2(xmin & ~3, ymin);
+        }
+        __syncthreads();
+        const uint8_t* img = a.src8 + (size_t)__builtin_amdgcn_readfirstlane(a.src_idx[item]) * a.src8_stride;
+        constexpr int SLOTS = R::NB * R::BH * R::LPR;        // 16-byte pieces of all boxes; piece i lands at LDS byte 16 i
+        constexpr int ITERS = (SLOTS + C::NT - 1) / C::NT;
+        // (all source addresses first -- they need the box origins from LDS -- then the LDS-DMAs back to back: an LDS read
+        // after a DMA makes the compiler wait for that DMA)
+        const uint8_t* from[ITERS];
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            const int i = min(tid + it * C::NT, SLOTS - 1);
+            const int b = i / (R::BH * R::LPR), rem = i - b * (R::BH * R::LPR), k = rem / R::LPR, p = rem - k * R::LPR;
+            const int2 o = info[b];
+            int y = o.y + k; y += (y < 0) ? rows : 0; y -= (y >= rows) ? rows : 0;
+            int x = o.x + 16 * p; x += (x < 0) ? W : 0; x -= (x >= W) ? W : 0;
+            from[it] = img + (unsigned)(y * a.src8_pitch + x);
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // keep every LDS read above the first DMA
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            if (tid + it * C::NT < SLOTS && !ABL(a, 16))
+                __builtin_amdgcn_global_load_lds((glb_void*)from[it], (lds_void*)(smem + (size_t)(it * C::NT + (tid & ~63)) * 16), 16, 0, 0);
+        }
+        __syncthreads();
+        if (j < D::MF && !ABL(a, 32)) {
+            const int2* X0 = reinterpret_cast<const int2*>(xy);
+            const int2* Y0 = reinterpret_cast<const int2*>(xy + rows);
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(smem);
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) {
+                const int m = j + q * D::MF;
+                const int2 xr = X0[m], yr = Y0[m];
+                const int2 o = info[q];
+                const uint8_t* box = sb + q * R::BOX - o.y * R::PITCH - o.x;
+                float r[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int X = ((h ? xr.y : xr.x) + ad) >> 5, Y = ((h ? yr.y : yr.x) + bd) >> 5;
+                    const uint8_t* t = box + (Y >> 5) * R::PITCH + (X >> 5);
+                    r[h] = bilerp(unit_u8(t[0]), unit_u8(t[1]), unit_u8(t[R::PITCH]), unit_u8(t[R::PITCH + 1]), X & 31, Y & 31);
+                }
+                vin[0][q] = make_float2(r[0], r[1]);
+            }
+        }
+        __syncthreads();                                     // boxes consumed before the exchange buffer is written
+    }
+    if (a.dbg_plane && j < D::MF) {                          // debug tap: what the gather produced (tests: bit-exact vs the oracle)
+        float2* o = reinterpret_cast<float2*>(a.dbg_plane + ((size_t)item * a.cols + x0 + line) * (size_t)(2 * HH));
+#pragma unroll
+        for (int q = 0; q < D::RF; ++q) o[j + q * D::MF] = vin[0][q];
+    }
     float2* const ex[1] = { lds + line * C::EPITCH };
-    if (!(a.ablate & 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
+    if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
     __syncthreads();                                         // exchange buffer fully consumed
     if (j < D::ML) {
 #pragma unroll
         for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
     }
     __syncthreads();
-    if (!(a.ablate & 2)) a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+    if (!ABL(a, 2)) a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
 }
 
 // row r within `radius` (cyclically) of the window centre, or -- rotation surfaces, whose source is point-symmetric --
@@ -623,13 +796,13 @@ __device__ __forceinline__ bool win_hit(int r, int centre, int rows, int radius,
 }
 
 template <int HH, int EPI>
-__global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
+__global__ __launch_bounds__((ICfg<HH, EPI>::NT), (ICfg<HH, EPI>::WPS)) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = ICfg<HH>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
+    using C = ICfg<HH, EPI>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
     constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
-    if (a.ablate & 8) return;
+    if (ABL(a, 8)) return;
     __shared__ float red_f[NW];
     __shared__ int red_i[NW];
     __shared__ double red_d[2][NW];
@@ -660,7 +833,7 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     const int x0 = bx * A_LX;
     float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
-    if (!(a.ablate & 1)) a_load_pre<C>(lds, a.tw_full, spec, a.cols, x0, tid);
+    if (!ABL(a, 1)) a_load_pre<C>(lds, a.tw_full, spec, a.cols, x0, tid);
     __syncthreads();
     float2 vin[1][DI::RF], vout[1][DI::RL];
     if (j < DI::MF) {
@@ -669,7 +842,7 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     }
     __syncthreads();                                         // natural buffer consumed before the exchange overwrites it
     float2* const ex[1] = { lds + line * C::EPITCH };
-    if (!(a.ablate & 4)) fft_chain<P, true, 1, WL>(vin, vout, j, ex, a.tw_i);
+    if (!ABL(a, 4)) fft_chain<P, true, 1, WL>(vin, vout, j, ex, a.tw_i);
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
 
@@ -733,14 +906,14 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
             atomicMax(a.maxbuf + 2 * item + plane, __float_as_uint(m2));   // non-negative floats order as uints
         }
         float2 fout[1][DF::RL];
-        if (!(a.ablate & 4)) fft_chain<P, false, 1, WL>(vout, fout, j, ex, a.tw_f);
+        if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vout, fout, j, ex, a.tw_f);
         __syncthreads();
         if (j < DF::ML) {
 #pragma unroll
             for (int q = 0; q < DF::RL; ++q) lds[line * C::NPITCH + j + q * DF::ML] = fout[0][q];
         }
         __syncthreads();
-        if (!(a.ablate & 2)) a_post_store<C>(lds, a.tw_full, spec, a.cols, x0, tid);
+        if (!ABL(a, 2)) a_post_store<C>(lds, a.tw_full, spec, a.cols, x0, tid);
     } else {
         // arg-max (column-major first strict max, Eigen maxCoeff visitor) + moments for GetInfo
         float best = -INFINITY; int bidx = 0x7FFFFFFF;
@@ -788,36 +961,65 @@ __global__ __launch_bounds__(ICfg<HH>::NT, ICfg<HH>::WPS) void kA_inv(AArgs a) {
     }
 }
 
-// tile geometry of the polar forward kernel for half length hh (the host sorts the gather table per tile)
-void polar_tile_layout(int hh, int* lines, int* npitch) {
-    *lines = hh >= 360 ? KCC_FLX360 : KCC_ALX; *npitch = hh + 1;
+// geometry of the forward A kernels for half length hh: lines per tile, threads per line, first-pass radix and stride
+// (thread (line, j), j < mf, owns points j + q*mf, q < rf), LDS bytes of the FFT buffers (the polar staging must fit
+// under max(this, its own size)); the host builds the polar gather tables from it
+FwdGeom fwd_geom(int hh) {
+    FwdGeom f{};
+#define X(n) if (hh == n) { using C = FCfg<n>; using D = Dir<C::P, false>; f.lines = C::LX; f.threads = C::T; f.rf = D::RF; f.mf = D::MF; f.lds_bytes = C::BYTES; \
+                      f.qs_opts[0] = D::RF % 2 == 0 ? D::RF / 2 : 1; f.qs_opts[1] = polar_qs_mid(D::RF); f.qs_opts[2] = 1; }
+    KCC_HALF_LIST(X)
+#undef X
+    return f;
+}
+// SRC_ROT8 box geometry (tests check the bounds exhaustively on the host)
+Rot8Geom rot8_geom(int hh) {
+    Rot8Geom r{};
+#define X(n) if (hh == n) { using R = Rot8Cfg<n>; r.band_rows = R::BR, r.bands = R::NB; r.box_rows = R::BH; r.pitch = R::PITCH; r.lds_bytes = (int)R::BYTES; }
+    KCC_HALF_LIST(X)
+#undef X
+    return r;
 }
 // columns [0, W/2] rounded up to whole kernel_fwd tiles: what the Hermitian-half Kzz transform reads of the zz plane
 int zz_half_columns(PlaneGeom g) { const int lx = a_lx(g.rows / 2); return std::min(g.cols, ((g.cols / 2) / lx + 1) * lx); }
-int argmax_blocks(PlaneGeom g) { return g.cols / a_lx(g.rows / 2); }
+// columns [0, min(W/2, need)] rounded up to whole tiles: what the even-half inverse row pass of the zero-phase image reads
+// when only its columns |c| <= need are consumed (the polar gather never leaves the inscribed circle)
+int shifted_columns(PlaneGeom g, int need) { const int lx = a_lx(g.rows / 2); return std::min(g.cols, (std::min(g.cols / 2, need) / lx + 1) * lx); }
+int argmax_blocks(PlaneGeom g) { return g.cols / inv_lx(g.rows / 2, EPI_ARGMAX); }
 
-template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a) {
+template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a, size_t min_lds = 0) {
     a.n_items = n_items;
     dim3 grid((a.cols / FCfg<HH>::LX) * n_items), block(FCfg<HH>::NT);
-    static const bool big_lds = (FCfg<HH>::BYTES > 65536) &&
-        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_fwd<HH, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FCfg<HH>::BYTES) == hipSuccess);
-    (void)big_lds;
-    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, FCfg<HH>::BYTES, s, a);
+    const size_t bytes = std::max(fwd_lds_bytes<HH, SRC>(), min_lds);
+    static size_t lds_cap = 65536;                           // largest dynamic LDS size this instantiation may launch with
+    if (bytes > lds_cap &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_fwd<HH, SRC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess)
+        lds_cap = bytes;
+    hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, bytes, s, a);
 }
 template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
     a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
-    const int nbx = a.cols / ICfg<HH>::LX;
-    if (a.zz_tiles > 0) a.zz_tiles = (a.cols / 2) / ICfg<HH>::LX + 1;          // columns [0, W/2] rounded up to whole tiles
-    dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + (epi_is_kfwd(EPI) ? nbx : 0)) * n_items : nbx * n_items * nz), block(ICfg<HH>::NT);
-    static const bool big_lds = (ICfg<HH>::BYTES > 65536) &&
-        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ICfg<HH>::BYTES) == hipSuccess);
+    using C = ICfg<HH, EPI>;
+    const int nbx = a.cols / C::LX;
+    // zz_tiles (flag -> tile count): columns [0, min(W/2, zz_tiles - 1)] rounded up to whole tiles
+    if (a.zz_tiles > 0) a.zz_tiles = std::min(a.cols / 2, a.zz_tiles - 1) / C::LX + 1;
+    dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + (epi_is_kfwd(EPI) ? nbx : 0)) * n_items : nbx * n_items * nz), block(C::NT);
+    static const bool big_lds = (C::BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
     (void)big_lds;
-    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, ICfg<HH>::BYTES, s, a);
+    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, C::BYTES, s, a);
 }
 
+// polar forward kernel for `qs` first-pass points per thread and segment (one of the sizes fwd_geom() offers)
+template <int HH> static void polar_launch(hipStream_t s, int n_items, const AArgs& a, int qs, size_t lds) {
+    constexpr int RF = Dir<typename FCfg<HH>::P, false>::RF;
+    if constexpr (RF % 2 == 0) { if (qs == RF / 2) { launchA_fwd_t<HH, SRC_POLAR_H>(s, n_items, a, lds); return; } }
+    if constexpr (polar_qs_mid(RF) > 1) { if (qs == polar_qs_mid(RF)) { launchA_fwd_t<HH, SRC_POLAR_T>(s, n_items, a, lds); return; } }
+    launchA_fwd_t<HH, SRC_POLAR_Q>(s, n_items, a, lds);
+}
 static AArgs base_args(PlaneGeom g, Tables t) {
     AArgs a{};
-    a.ablate = g_ablate; a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full; a.twI_f = t.halfI_f; a.twI_i = t.halfI_i;
+    a.ablate = ablate_flags(); a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full; a.twI_f = t.halfI_f; a.twI_i = t.halfI_i;
     return a;
 }
 
@@ -842,19 +1044,39 @@ void launch_A_fwd_plane(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 #undef CALL
 }
 void launch_A_fwd_rot(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* arena_img, size_t img_stride, int img_pitch,
-                      const int* img_slot, const int* rot_tab, const int* rot_index, float2* dst, size_t dst_stride) {
+                      const int* img_slot, const int* rot_tab, const int* rot_index, float2* dst, size_t dst_stride, float* dbg_plane) {
     AArgs a = base_args(g, t);
     a.src = arena_img; a.src_stride = img_stride; a.src_pitch = img_pitch; a.src_idx = img_slot; a.rot_tab = rot_tab; a.rot_index = rot_index;
-    a.spec = dst; a.spec_stride = dst_stride;
+    a.spec = dst; a.spec_stride = dst_stride; a.dbg_plane = dbg_plane;
 #define CALL(HH) launchA_fwd_t<HH, SRC_ROT>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
 void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float* S, size_t s_stride,
-                        int H, int W, const uint32_t* polar_tab, float2* dst, size_t dst_stride) {
+                        int H, int W, const PolarPlan& pp, float2* dst, size_t dst_stride, float* dbg_plane) {
     AArgs a = base_args(g, t);
-    a.src = S; a.src_stride = s_stride; a.H = H; a.W = W; a.SP = H + 2; a.polar_tab = polar_tab; a.spec = dst; a.spec_stride = dst_stride;
-#define CALL(HH) launchA_fwd_t<HH, SRC_POLAR>(s, n_items, a)
+    a.src = S; a.src_stride = s_stride; a.H = H; a.W = W; a.SP = H + 2; a.spec = dst; a.spec_stride = dst_stride;
+    a.polar_chunks = pp.chunks; a.polar_seg_first = pp.seg_first; a.polar_pts = pp.pts; a.dbg_plane = dbg_plane;
+#define CALL(HH) polar_launch<HH>(s, n_items, a, pp.qs, pp.lds_bytes)
+    DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
+}
+void launch_A_fwd_u8(hipStream_t s, int n_items, PlaneGeom g, Tables t, const uint8_t* src, size_t src_stride, int src_pitch,
+                     uint8_t* keep, size_t keep_stride, int keep_pitch, const int* keep_slot, float2* dst, size_t dst_stride) {
+    AArgs a = base_args(g, t);
+    a.src8 = src; a.src8_stride = src_stride; a.src8_pitch = src_pitch;
+    a.dst8 = keep; a.dst8_stride = keep_stride; a.dst8_pitch = keep_pitch; a.dst8_slot = keep_slot;
+    a.spec = dst; a.spec_stride = dst_stride;
+#define CALL(HH) launchA_fwd_t<HH, SRC_U8>(s, n_items, a)
+    DISPATCH_HALF(g.rows / 2, CALL)
+#undef CALL
+}
+void launch_A_fwd_rot8(hipStream_t s, int n_items, PlaneGeom g, Tables t, const uint8_t* arena_u8, size_t img_stride, int img_pitch,
+                       const int* img_slot, const int* rot_tab, const int* rot_index, float2* dst, size_t dst_stride, float* dbg_plane) {
+    AArgs a = base_args(g, t);
+    a.src8 = arena_u8; a.src8_stride = img_stride; a.src8_pitch = img_pitch; a.src_idx = img_slot; a.rot_tab = rot_tab; a.rot_index = rot_index;
+    a.spec = dst; a.spec_stride = dst_stride; a.dbg_plane = dbg_plane;
+#define CALL(HH) launchA_fwd_t<HH, SRC_ROT8>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
@@ -867,10 +1089,10 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
 #undef CALL
 }
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride, bool even_half) {
+                          float* S, size_t s_stride, int need_cols) {
     AArgs a = base_args(g, t);
     a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.real_out = S; a.real_stride = s_stride;
-    a.zz_tiles = even_half ? 1 : 0;                          // (the launcher turns the flag into the tile count)
+    a.zz_tiles = need_cols > 0 ? need_cols + 1 : 0;          // (the launcher turns "columns <= need" into the tile count)
 #define CALL(HH) launchA_inv_t<HH, EPI_SHIFTED>(s, n_items, 1, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
@@ -881,7 +1103,7 @@ void launch_A_inv_kernel_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, 
     AArgs a = base_args(g, t);
     a.spec = buf; a.spec_stride = item_stride; a.plane_stride = plane_stride; a.fn = fn; a.maxbuf = maxbuf; a.energy = energy;
     a.plane_first = plane_first; a.n_planes = n_planes;
-    a.zz_tiles = (zz_half && plane_first == 0 && n_planes == 2) ? 1 : 0;      // (the launcher turns the flag into the tile count)
+    a.zz_tiles = (zz_half && plane_first == 0 && n_planes == 2) ? g.cols / 2 + 1 : 0;      // (the launcher turns it into the tile count)
     if (fn.type == 1) {
 #define CALL(HH) launchA_inv_t<HH, EPI_KFWD_GAUSS>(s, n_items, n_planes, a)
         DISPATCH_HALF(g.rows / 2, CALL)
@@ -969,11 +1191,6 @@ template <int N, int MODE> struct BCfg {
 };
 
 template <int RR>
-__device__ __forceinline__ void zero_fill(float2 (&v)[RR]) {
-#pragma unroll
-    for (int q = 0; q < RR; ++q) v[q] = make_float2(0.f, 0.f);
-}
-template <int RR>
 __device__ __forceinline__ void load_strided(float2 (&v)[RR], const float2* __restrict__ p, int stride, bool ok) {
     if (ok) {
 #pragma unroll
@@ -994,13 +1211,13 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     using C = BCfg<N, MODE>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
     static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
     float2* lds = reinterpret_cast<float2*>(smem);
-    if (a.ablate & 8) return;
+    if (ABL(a, 8)) return;
     const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
     const int item = blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
     const bool valid0 = k < a.hr;
-    const bool valid = valid0 && !(a.ablate & 1);          // loads
-    const bool vst = valid0 && !(a.ablate & 2);            // stores
-    const bool nofft = a.ablate & 4;
+    const bool valid = valid0 && !ABL(a, 1);          // loads
+    const bool vst = valid0 && !ABL(a, 2);            // stores
+    const bool nofft = ABL(a, 4);
     const size_t loff = (size_t)k * N + j;
     constexpr int NVM = C::NV;
     float2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
@@ -1190,7 +1407,7 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
 
 static BArgs base_bargs(PlaneGeom g, Tables t) {
     BArgs a{};
-    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = g_ablate;
+    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = ablate_flags();
     return a;
 }
 
@@ -1211,10 +1428,10 @@ void launch_B_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float
 #undef CALL
 }
 void launch_B_fwd_abs_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float2* dstF_base, size_t dstF_stride, const int* dst_slot, float2* tmp, size_t tmp_stride, bool even_half) {
+                          float2* dstF_base, size_t dstF_stride, const int* dst_slot, float2* tmp, size_t tmp_stride, int need_cols) {
     BArgs a = base_bargs(g, t);
     a.src = src; a.src_stride = src_stride; a.dst = dstF_base; a.dst_stride = dstF_stride; a.dst_slot = dst_slot;
-    a.dst2 = tmp; a.dst2_stride = tmp_stride; a.zz_half = even_half ? zz_half_columns(g) : 0;
+    a.dst2 = tmp; a.dst2_stride = tmp_stride; a.zz_half = need_cols > 0 ? shifted_columns(g, need_cols) : 0;
 #define CALL(N) launchB_t<N, B_FWD_ABS_INV>(s, n_items, a)
     DISPATCH_LINE(g.cols, CALL)
 #undef CALL
@@ -1373,25 +1590,6 @@ __global__ void k_make_shifted(const float* __restrict__ p, float* __restrict__ 
 }
 void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W) {
     hipLaunchKernelGGL(k_make_shifted, dim3((H * W + 255) / 256), dim3(256), 0, s, p, S, H, W);
-}
-
-__global__ void k_dbg_rot(const float* __restrict__ img, const int* __restrict__ tab, float* __restrict__ out, int H, int W, int PH) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < H * W) {
-        const int r = i % H, c = i / H;
-        out[i] = rot_sample(img, H, PH, W, tab[c], tab[W + c], tab[2 * W + r], tab[2 * W + H + r]);
-    }
-}
-void launch_dbg_rot(hipStream_t s, const float* img, const int* rot_tab, float* out, int H, int W, int PH) {
-    hipLaunchKernelGGL(k_dbg_rot, dim3((H * W + 255) / 256), dim3(256), 0, s, img, rot_tab, out, H, W, PH);
-}
-__global__ void k_dbg_polar(const float* __restrict__ S, const uint32_t* __restrict__ tab, float* __restrict__ out,
-                            int SP, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // out is column-major PD x PC == tab order [PC][PD]
-    if (i < n) out[i] = polar_sample(S, SP, tab[i]);
-}
-void launch_dbg_polar(hipStream_t s, const float* S, const uint32_t* tab, float* out, int H, int W, int PD, int PC) {
-    hipLaunchKernelGGL(k_dbg_polar, dim3((PD * PC + 255) / 256), dim3(256), 0, s, S, tab, out, H + 2, PD * PC);
 }
 
 __global__ void k_transpose_c(const float2* __restrict__ src, float2* __restrict__ dst, int R, int C) {

@@ -24,11 +24,12 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
-           "nik_profile_enable", "nik_profile_read", "nik_dbg_set_ablate", "nik_set_streams",
+           "nik_profile_enable", "nik_profile_read", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
-           "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop"]
+           "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
+           "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom"]
 
 
 class NikConfig(C.Structure):
@@ -182,8 +183,12 @@ def load():
         L.nik_tracker_push_dev.argtypes = [P, I, P, P]
         L.nik_tracker_push_u8.argtypes = [P, P, I, P]
         L.nik_tracker_keyframes.argtypes = [P, P, I, P]
-        L.nik_dbg_set_ablate.argtypes = [I]
         L.nik_profile_read.argtypes = [P, P, I, P]
+        L.nik_host_polar_plan.argtypes = [I, I, I, I, P, P, P, P, P]
+        L.nik_host_free.argtypes = [P]
+        L.nik_host_free.restype = None
+        L.nik_host_rot_terms.argtypes = [I, I, C.c_float, P]
+        L.nik_host_rot8_geom.argtypes = [I, P]
         _lib = L
     return _lib
 
@@ -194,6 +199,43 @@ def _p(a):
 
 def _i32(seq):
     return np.ascontiguousarray(np.asarray(seq, dtype=np.int32))
+
+
+def host_polar_plan(H, W, PD, PC):
+    """The polar gather plan nik_create builds for this geometry (host only, no GPU): dict of numpy arrays."""
+    L = load()
+    dims = np.zeros(8, np.int32)
+    ch, sf, pts = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    nch = C.c_int()
+    rc = L.nik_host_polar_plan(H, W, PD, PC, _p(dims), C.byref(ch), C.byref(nch), C.byref(sf), C.byref(pts))
+    if rc:
+        raise RuntimeError("nik_host_polar_plan: %d %s" % (rc, L.nik_last_error(None).decode()))
+    qs, nseg, tiles, lines, threads, rf, mf, lds = (int(v) for v in dims)
+    def take(ptr, n, dt):
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(dt)), shape=(n,)).copy()
+        L.nik_host_free(ptr)
+        return a
+    out = dict(qs=qs, nseg=nseg, tiles=tiles, lines=lines, threads=threads, rf=rf, mf=mf, lds_bytes=lds,
+               chunks=take(ch, max(nch.value, 1), C.c_uint32)[:nch.value],
+               seg_first=take(sf, tiles * nseg + 1, C.c_int32),
+               pts=take(pts, tiles * rf * lines * threads * 4, C.c_uint32).reshape(tiles, rf, lines * threads, 4))
+    return out
+
+
+def host_rot_terms(H, W, degree):
+    out = np.zeros(2 * W + 2 * H, np.int32)
+    rc = load().nik_host_rot_terms(H, W, C.c_float(degree), _p(out))
+    if rc:
+        raise RuntimeError("nik_host_rot_terms: %d" % rc)
+    return out[:W], out[W:2 * W], out[2 * W:2 * W + H], out[2 * W + H:]
+
+
+def host_rot8_geom(H):
+    g = np.zeros(5, np.int32)
+    rc = load().nik_host_rot8_geom(H, _p(g))
+    if rc:
+        raise RuntimeError("nik_host_rot8_geom: %d" % rc)
+    return dict(band_rows=int(g[0]), bands=int(g[1]), box_rows=int(g[2]), pitch=int(g[3]), lds_bytes=int(g[4]))
 
 
 def camera_maps(K, D, W, H):

@@ -1,7 +1,7 @@
 # usage: bash tools/runvar.sh <suffix> [<suffix> ...]   -- benchmark tuning variants of the library (NIK_LIB)
 cd $GRAFT_REPO_ROOT
 for v in "" "$@"; do
-  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip$v.so python bench.py --steps 5 --warmup 2 --cpu-sample 8 > gpurun_out/var$v.json 2>gpurun_out/var$v.err || echo "FAIL $v"
+  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip$v.so python bench.py --steps ${STEPS:-20} --warmup 3 --cpu-sample 8 > gpurun_out/var$v.json 2>gpurun_out/var$v.err || echo "FAIL $v"
 done
 python - "$@" <<PY
 import json,sys,os
