@@ -331,6 +331,11 @@ int nik_dbg_rotate(nik_ctx* ctx, nik_frame f, int degree2, float* out_colmajor);
 int nik_dbg_polar(nik_ctx* ctx, const float* x_colmajor, float* out_colmajor /*PD x PC*/);
 
 
+/* The response surface g = IFFT(G) of one EstimateTrans call (correlation_flow.cc:171-173), which the hot path never stores.
+ * which 0: rotation stage of (key, cur) -> PD x PC;  which 1: translation stage against cur's image de-rotated by
+ * degree2/2 degrees -> H x W.  Column-major like every real plane of the reference. */
+int nik_dbg_response(nik_ctx* ctx, int which, nik_frame key, nik_frame cur, int degree2, float* g_colmajor);
+
 /* ---- host-side gather tables (tests only; no GPU needed) --------------------------------------
  * The tables the two gather kernels consume, built exactly as nik_create builds them, so that CPU tests can replay
  * the kernels' staging / sampling arithmetic against the oracle (tests/test_host_tables.py). */

@@ -854,12 +854,19 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
 
 // Build the Kzz cache of every listed key slot that lacks it (both families), on lane 0:
 //   Kzz' = FFT( kernel( IFFT(|Z|^2) ) ) (not yet divided by its max) and Mzz = max|kernel|   (correlation_flow.cc:160,164)
+static int ensure_kzz_run(nik_ctx* c, Lane& L, const std::vector<nik_frame>& todo);
 static int ensure_kzz(nik_ctx* c, int n, const nik_frame* keys) {
     std::vector<nik_frame> todo;
     for (int i = 0; i < n; ++i)
         if (!c->slot_kzz[keys[i]]) { c->slot_kzz[keys[i]] = 2; todo.push_back(keys[i]); }      // 2 = scheduled in this pass
     if (todo.empty()) return NIK_OK;
     Lane& L = c->lanes[0];
+    int rc = ensure_kzz_run(c, L, todo);
+    // whatever was scheduled but not enqueued (an error on the way) stays uncached
+    for (nik_frame f : todo) if (c->slot_kzz[f] == 2) c->slot_kzz[f] = 0;
+    return rc;
+}
+static int ensure_kzz_run(nik_ctx* c, Lane& L, const std::vector<nik_frame>& todo) {
     int rc;
     for (size_t b = 0; b < todo.size(); b += (size_t)c->max_batch) {
         const int m = (int)std::min(todo.size() - b, (size_t)c->max_batch);
@@ -1005,6 +1012,17 @@ int nik_track_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const nik_fram
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, cur_dst[i], false))) return rc;
+    // a slot that is both read as a key and overwritten, or overwritten twice, would make the results depend on how the
+    // batch is split over the streams: reject it
+    {
+        std::vector<uint8_t> mark(c->max_frames, 0);
+        for (int i = 0; i < n; ++i) mark[keys[i]] = 1;
+        for (int i = 0; i < n; ++i) {
+            if (mark[cur_dst[i]] == 1) return fail(c, NIK_ERR_INVALID_ARG, "slot %d is both a key and a destination of the batch", cur_dst[i]);
+            if (mark[cur_dst[i]] == 2) return fail(c, NIK_ERR_INVALID_ARG, "slot %d is a destination twice in the batch", cur_dst[i]);
+            mark[cur_dst[i]] = 2;
+        }
+    }
     if ((rc = pose_call(c, n, d_gray, keys, cur_dst, not_large_rotation, res))) return rc;
     return sync ? drain_all(c) : NIK_OK;
 }
@@ -1053,6 +1071,7 @@ int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* b
 // rotation stage only (EstimateTrans on the cached polar spectra): PSR_r and arg-max row per candidate
 static int rotation_call(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, float* psr_rot, int* rot_row) {
     int rc;
+    if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;      // enqueue_estimate's cached branch reads the keys' Kzz
     struct Part { Lane* L; Call* call; int b, m; };
     std::vector<Part> parts;
     const int nl = lanes_for(c, n);
@@ -1222,6 +1241,50 @@ int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
     return NIK_OK;
+}
+
+// The response surface g = IFFT(G) of one EstimateTrans call (correlation_flow.cc:171-173) -- the plane whose arg-max and
+// moments the hot path reduces on registers without ever storing it.  Tests use it to MEASURE the float32 noise between
+// this implementation and the oracle (the rotation-tie tolerance is derived from that measurement).
+//   which 0: rotation stage, z = key's polar spectrum, x = cur's polar spectrum          -> PD x PC (column-major)
+//   which 1: translation stage, z = key's spectrum, x = FFT(RotateArray(cur image, degree2 / 2 degrees)) -> H x W
+int nik_dbg_response(nik_ctx* c, int which, nik_frame key, nik_frame cur, int degree2, float* g) {
+    if (!c || !g || (which != 0 && which != 1)) return NIK_ERR_INVALID_ARG;
+    int rc;
+    if ((rc = check_kernel(c)) || (rc = nik_synchronize(c)) || (rc = check_slot(c, key, true)) || (rc = check_slot(c, cur, true))) return rc;
+    if (c->kzz_cache && (rc = ensure_kzz(c, 1, &key))) return rc;
+    Lane& L = c->lanes[0]; hipStream_t s = L.stream;
+    if ((rc = begin_call(c, L)) || (rc = depend_on_slot(c, L, 0, key)) || (rc = depend_on_slot(c, L, 0, cur))) return rc;
+    if ((rc = stage_pose_indices(c, L, 1, &key, &cur, 1, false))) return rc;
+    Family& f = which ? c->img : c->pol;
+    if (which == 0) {
+        enqueue_estimate(c, L, 1, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
+                         c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, nullptr, 1);
+    } else {
+        std::vector<int> terms((size_t)2 * c->W + 2 * c->H);
+        rotation_terms(c->H, c->W, (float)degree2 * 0.5f, terms.data());
+        if (!c->rot_one) HIP_TRY(c, hipMalloc(&c->rot_one, sizeof(int) * (terms.size() + 2)));
+        HIP_TRY(c, hipMemcpyAsync(c->rot_one, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
+        HIP_TRY(c, hipMemsetAsync(didx(L, IX_ROTIDX), 0, sizeof(int), s));
+        if (!(c->slot_kind[cur] & 1) && (rc = ensure_f32_images(c, L, 0, 1, &cur))) return rc;
+        if (c->slot_kind[cur] & 1)
+            launch_A_fwd_rot8(s, 1, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_TIMG), c->rot_one, didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
+        else
+            launch_A_fwd_rot(s, 1, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_one, didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
+        if (c->cfg.kernel == 1) {
+            launch_B_fwd(s, 1, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
+            enqueue_estimate(c, L, 1, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems, didx(L, IX_TKEY), L.trans_res, nullptr, 1);
+        } else {
+            enqueue_estimate(c, L, 1, c->img, true, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems, didx(L, IX_TKEY), L.trans_res, nullptr, 1);
+        }
+    }
+    float* d_g = reinterpret_cast<float*>(L.kbuf);            // (the kernel planes are consumed by now)
+    launch_A_inv_real(s, 1, f.g, f.t, L.gbuf, c->spec_max, d_g, f.real_elems);
+    HIP_TRY(c, hipMemcpyAsync(g, d_g, sizeof(float) * f.real_elems, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipGetLastError());
+    L.cur->has_pose = false;
+    if ((rc = end_call(c, L))) return rc;
+    return nik_synchronize(c);
 }
 
 // ---- host-side gather tables (tests; no device needed) -------------------------------------------

@@ -127,7 +127,7 @@ __device__ __forceinline__ float kernel_value(const KernelFn& fn, float xz, floa
         return pow_generic(xz + fn.offset, fn.power);
     } else {
         // gaussian: exp(-1/sigma^2 * (xx + zz - 2 xz)/N)   (correlation_flow.cc:189-190)
-        return __expf((gauss_bias - 2.f * xz) * gauss_scale);
+        return expf((gauss_bias - 2.f * xz) * gauss_scale);
     }
 }
 

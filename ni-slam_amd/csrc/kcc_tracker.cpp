@@ -197,8 +197,11 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     std::vector<nik_pose_result> res(n);
     std::vector<nik_frame> keys(n);
     int rc, start = 0;
+    memset(out, 0, sizeof(out[0]) * (size_t)n);
+    // on an error: frames that did not become keyframes give their slots back; outputs of unprocessed frames stay zero
+    auto bail = [&](int code) { for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]); return code; };
     // the spectra of a frame do not depend on the keyframe: all n frames in one batch
-    if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return rc;
+    if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return bail(rc);
     if (!t->init) { first_frame(t, slot[0], out[0]); start = 1; }
     while (start < n) {
         // Register the next `depth` frames against the current keyframe in one batch.  The registrations are
@@ -207,7 +210,7 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
         // little work is thrown away while the batches stay as large as the sequence allows.
         const int m = std::min(n - start, std::max(1, t->spec_depth));
         for (int i = 0; i < m; ++i) keys[i] = t->key_slot;
-        if ((rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data()))) return rc;
+        if ((rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data()))) return bail(rc);
         int i = 0; bool inserted = false;
         while (i < m && !inserted) { inserted = apply_result(t, res[i], slot[start + i], out[start + i]); ++i; }
         t->spec_depth = inserted ? std::min(t->max_batch, std::max(4, 2 * i)) : std::min(t->max_batch, 2 * std::max(1, t->spec_depth));

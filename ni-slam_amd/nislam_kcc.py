@@ -23,7 +23,7 @@ NIK_ERR_HIP, NIK_ERR_CAPACITY, NIK_ERR_NOT_READY = -4, -5, -6
 EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_stream", "nik_synchronize",
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
-           "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar",
+           "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar", "nik_dbg_response",
            "nik_profile_enable", "nik_profile_read", "nik_set_streams",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
@@ -176,6 +176,7 @@ def load():
         L.nik_dbg_ifft.argtypes = [P, I, P, P]
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
         L.nik_dbg_polar.argtypes = [P, P, P]
+        L.nik_dbg_response.argtypes = [P, I, I, I, I, P]
         L.nik_profile_enable.argtypes = [P, I]
         L.nik_tracker_create.argtypes = [P, C.POINTER(NikTrackerConfig), C.POINTER(P)]
         L.nik_tracker_destroy.argtypes = [P]
@@ -437,6 +438,13 @@ class CorrelationFlow:
         x = np.ascontiguousarray(x, np.float32)
         out = np.empty((self.PC, self.PD), np.float32)
         self._chk(self._L.nik_dbg_polar(self._ctx, _p(x), _p(out)))
+        return out
+
+    def dbg_response(self, which, key, cur, degree2=0):
+        """g = IFFT(G) of EstimateTrans: which 0 -> rotation surface (PC, PD), which 1 -> translation surface (W, H) of
+        cur's image de-rotated by degree2/2 degrees"""
+        out = np.empty((self.PC, self.PD) if which == 0 else (self.W, self.H), np.float32)
+        self._chk(self._L.nik_dbg_response(self._ctx, int(which), int(key), int(cur), int(degree2), _p(out)))
         return out
 
 

@@ -331,7 +331,7 @@ def test_other_reference_geometries(H, W):
     """the sizes of the reference's other shipped configs (config_geekplus.yaml, config_HD.yaml: radix 7 and 5^2),
     the config-4 size and a pyramid level; polar 720 x 480 as shipped."""
     geom = dict(H=H, W=W, PD=720, PC=480)
-    n = 2
+    n = 8 if (H, W) in ((448, 448), (1200, 1600)) else 2          # the two shipped non-NTU configs get 8 pairs each
     cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
     keys, curs, motions = synth.make_batch(n, H, W, seed0=1300 + H, max_shift=min(H, W) // 12, max_theta=8.0)
     x = np.random.default_rng(H).random((W, H), dtype=np.float32)
