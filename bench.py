@@ -1,13 +1,21 @@
 #!/usr/bin/env python
-"""bench.py -- frame-pairs/s of the KCC front end (ComputeIntermedium(current) + ComputePose(key, current,
-not_large_rotation=true)) on 640x480 synthetic ground texture, inputs resident in HBM.
+"""bench.py -- throughput of the KCC front end on synthetic ground texture, inputs resident in HBM.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
-A step = one pass of the hot path over a batch of B frame pairs per GPU (weak scaling: B per rank fixed).
-Multi-GPU: one process per GPU (torch.distributed, RCCL); pairs shard across ranks with no data-path
-collective; one 4-double all-reduce per step carries the residual/PSR statistics (north_star).
+Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.  The default workload
+("pairs", BASELINE configs[1]) is the headline: a step = ComputeIntermedium(current) + ComputePose(key, current,
+not_large_rotation=true) over a batch of B 640x480 frame pairs per GPU (weak scaling: B per rank fixed).
+Multi-GPU: one process per GPU; pairs shard across ranks with no data-path collective; per step the residual statistics
+[sum PSR_t, sum PSR_r, sum |t|^2, count] are reduced on each device and all-reduced with RCCL through the library's own
+C ABI (nik_group_allreduce_residual), asynchronously.  The timed loop is the same code for N = 1 and N > 1.
+
+Other workloads (`--workload`, N = 1; same JSON schema, each with its own algorithmic bytes per unit from SURVEY 8(d)):
+  sequence  configs[1] as a real sequence through the C++ tracker (frames/s)
+  pyramid   configs[2]: 4-level coarse-to-fine, radius-4 lookup, batch 32 (pairs/s)
+  hd        configs[3] geometry on one GPU: 1280x720 RGB -> luma -> pair (pairs/s)
+  loop4096  configs[4]: 1 query x 4096 resident key frames, exact two-hypothesis search and top-16 short list (candidates/s)
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -18,11 +26,390 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-H, W, PD, PC = 480, 640, 720, 480
-# algorithmic HBM bytes of one 640x480 frame pair (every 2-D FFT = 1 read + 1 write of its
-# planes, all pointwise work fused, Kzz NOT cached -- the reference recomputes it per pair).
-BYTES_PER_PAIR = 40.63e6
 HBM_PEAK = 8.0e12          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def _planes(H, W, PD, PC):
+    N = H * W
+    return N, 4.0 * N, 8.0 * (H // 2 + 1) * W, 4.0 * PD * PC, 8.0 * (PD // 2 + 1) * PC      # N, R, C, Rp, Cp
+
+
+def intermedium_bytes(H, W, PD, PC):
+    N, R, C, Rp, Cp = _planes(H, W, PD, PC)
+    return (N + C) + (C + R) + (R + Rp) + (Rp + Cp)
+
+
+def algorithmic_bytes(H, W, PD, PC, kzz_cached=False, hypotheses=1, with_intermedium=True):
+    """SURVEY.md 8(d) accounting: every 2-D FFT = one read of its input plane(s) + one write of its output plane, all
+    pointwise work fused, gathers read their source once; Kzz recomputed per pair unless kzz_cached."""
+    N, R, C, Rp, Cp = _planes(H, W, PD, PC)
+
+    def stage(r, c):                       # EstimateTrans: Kzz (2 FFTs), Kxz (2 FFTs, two input spectra), g (1 FFT)
+        return (0.0 if kzz_cached else 2 * (r + c)) + (2 * (r + c) + c) + (r + c)
+    return (intermedium_bytes(H, W, PD, PC) if with_intermedium else 0.0) + stage(Rp, Cp) + hypotheses * ((R + C) + stage(R, C))
+
+
+def _profile(cf, run_once, steps):
+    """per-kernel HIP-event timings on ONE stream (durations are only meaningful without co-running kernels)"""
+    cf.set_streams(1)
+    cf.profile_enable(True)
+    for _ in range(steps):
+        run_once()
+    st = cf.profile_read()
+    cf.profile_enable(False)
+    cf.set_streams(int(os.environ.get("NIK_STREAMS", "2")))
+    tot = sum(s["ms"] for s in st) or 1.0
+    kernels = []
+    for s in sorted(st, key=lambda s: -s["ms"]):
+        if not s["launches"]:
+            continue
+        avg_ms = s["ms"] / s["launches"]
+        bpl = s["bytes"] / s["launches"]
+        kernels.append(dict(name=s["name"], avg_ms=round(avg_ms, 4), share=round(s["ms"] / tot, 4), bytes_per_launch=bpl,
+                            gbps=round(bpl / (avg_ms * 1e-3) / 1e9, 1)))
+    return kernels
+
+
+def _roofline(kernels, batch):
+    """the kernel with the largest share of GPU time against the HBM roofline.  `achieved` uses the ALGORITHMIC bytes of the
+    launch; `traffic` is that kernel's MEASURED HBM bytes per launch from the committed rocprofv3 --pmc summary
+    (not re-measured in this run: traffic_source names the file) and frac_moved_bytes prices the kernel on those bytes."""
+    if not kernels:
+        return None
+    top = kernels[0]
+    ach = top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9
+    traffic, src = None, None
+    try:
+        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        pm = json.load(open(f))
+        if pm.get("pairs_per_launch") == batch:
+            traffic, src = pm["traffic_bytes_per_launch"].get(top["name"]), "profiles/" + os.path.basename(f)
+    except Exception:
+        pass
+    r = dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4),
+             traffic=traffic, traffic_source=src, avg_ms=top["avg_ms"], bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
+    if traffic:
+        r["frac_moved_bytes"] = round(traffic / (top["avg_ms"] * 1e-3) / HBM_PEAK, 4)
+    return r
+
+
+def _line(metric, unit, value, world, args, ms_per_step, workload, bytes_per_unit, extra_cfg=None, **more):
+    out = {"metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "data": "synthetic",
+           "config": dict({"workload": workload, "streams_per_gpu": int(os.environ.get("NIK_STREAMS", "2"))}, **(extra_cfg or {})),
+           "path_roofline": {"bytes_per_unit": bytes_per_unit, "achieved_GBps": round(value / world * bytes_per_unit / 1e9, 1),
+                             "frac_of_8TBps": round(value / world * bytes_per_unit / HBM_PEAK, 4)}}
+    out.update(more)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank):
+    from kcc_helpers import check_pose_parity, imposed_rerun
+    H, W, PD, PC = 480, 640, 720, 480
+    B = args.batch
+    U = B if args.unique <= 0 else min(args.unique, B)
+    gb = int(os.environ.get("NIK_BENCH_GLOBAL_BATCH", "0"))
+    if gb:      # test hook: ONE global batch, this rank takes its contiguous shard (sharded == unsharded can then be checked)
+        gk, gc_, _ = synth.make_unique_batch(gb, H, W, seed0=777, max_theta=10.0)
+        b0, e0 = N.Group.shard(gb, world, rank)
+        keys_u8, curs_u8, B = gk[b0:e0], gc_[b0:e0], e0 - b0
+        U = B
+    else:
+        keys_u8, curs_u8, motions = synth.make_unique_batch(U, H, W, seed0=1000 * (rank + 1), max_theta=10.0)
+    reps = (B + U - 1) // U
+    d_keys = torch.from_numpy(np.tile(keys_u8, (reps, 1, 1))[:B]).to(dev)
+    d_curs = torch.from_numpy(np.tile(curs_u8, (reps, 1, 1))[:B]).to(dev)
+    torch.cuda.synchronize()
+    cfg = N.default_config()
+    cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
+    key_slots, cur_slots = list(range(B)), list(range(B, 2 * B))
+    cf.intermedium_batch_dev(d_keys.data_ptr(), B, key_slots)       # keyframe spectra: prepared before the timed region
+    cf.synchronize()
+
+    # the residual all-reduce: through the library's nik_group (RCCL inside the C ABI).  Test hook NIK_BENCH_BACKEND=gloo
+    # (several ranks on one device, where RCCL cannot form a communicator): device-side reduction + torch.distributed.
+    comm, grp, stats_t = "nik_group (single GPU: no collective)", None, None
+    if world > 1 and os.environ.get("NIK_BENCH_BACKEND", "nccl") != "nccl":
+        cf.set_residual_stats(True)
+        stats_t = torch.zeros(4, dtype=torch.float64)
+        comm = "device-side reduction + torch.distributed(%s) all-reduce [test hook]" % os.environ["NIK_BENCH_BACKEND"]
+    else:
+        try:
+            uid = None
+            if world > 1:
+                t = torch.from_numpy(N.Group.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+                dist.broadcast(t, src=0)
+                uid = t.cpu().numpy()
+                comm = "nik_group: RCCL all-reduce of 4 doubles per step inside the C ABI"
+            grp = N.Group.rank(cf, rank, world, uid)
+        except Exception as e:                                   # keep the measurement alive; say so in the line
+            grp = None
+            cf.set_residual_stats(True)
+            stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
+            comm = "FALLBACK torch.distributed all-reduce (nik_group failed: %s)" % str(e)[:200]
+
+    # The library keeps two calls in flight per stream; results of step k are final once step k+2 has been queued (or after
+    # synchronize()).  Nothing in the loop touches per-pair results on the host.
+    ring = [(N.NikPoseResult * B)() for _ in range(3)]
+    state = {"k": 0}
+
+    def step():
+        k = state["k"]
+        res = cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=False, res=ring[k % 3])
+        if grp is not None:
+            grp.allreduce_residual(wait=False)                   # device-side reduction + RCCL, asynchronous
+        elif world > 1:
+            stats_t.copy_(torch.from_numpy(cf.residual_stats()))
+            dist.all_reduce(stats_t)
+        state["k"] = k + 1
+        return res
+
+    for _ in range(args.warmup):
+        res = step()
+    cf.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    cf.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    stats = grp.residual_result() if grp is not None else (stats_t.cpu().numpy() if stats_t is not None else None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    pairs_per_s = B * world / (dt / args.steps)
+    last = [r.as_dict() for r in res]                               # the final timed step's per-pair results (this rank)
+
+    # extra (not the headline): the same workload with the per-keyframe Kzz cache (SURVEY 8d "Kzz cached")
+    pairs_per_s_cached = None
+    if not args.no_cached and world == 1:
+        cf.set_kzz_cache(True)
+        for _ in range(2):
+            step()
+        cf.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        cf.synchronize()
+        pairs_per_s_cached = B / ((time.perf_counter() - t1) / args.steps)
+        cf.set_kzz_cache(False)
+
+    if os.environ.get("NIK_BENCH_DUMP"):                            # test hook: this rank's results of the last timed step
+        json.dump(dict(rank=rank, world=world, results=last, stats=None if stats is None else [float(v) for v in stats]),
+                  open(os.environ["NIK_BENCH_DUMP"] + ".%d" % rank, "w"))
+    out = None
+    if rank == 0:
+        kernels = [] if args.no_profile else _profile(cf, lambda: cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=True),
+                                                       max(2, min(args.steps, 5)))
+        # ---- CPU baseline: the oracle (a dependency-free port; the reference itself is unbuildable here).  This leg is the
+        # only place bench.py touches oracle/; its per-pair outputs double as a parity spot check of the last timed step.
+        cpu, parity_ok = None, None
+        if args.cpu_sample > 0 and world == 1:
+            from oracle import kcc_oracle as ko
+            ocfg = ko.default_config()
+            ncores = os.cpu_count() or 1
+            ns = min(args.cpu_sample, U)
+            # the oracle allocates plane-sized temporaries per call (like the reference's Eigen temporaries); on the 2x64-core
+            # host its throughput peaks near 32 threads (tools/cpu_scale.py), so that is what is reported
+            nthr = min(ncores, ns, 32)
+            poses, infos, dbgs, secs_all = ko.track_pairs(ocfg, keys_u8[:ns], curs_u8[:ns], True, faithful=False, nthreads=nthr)
+            parity_ok = all(check_pose_parity(last[i], poses[i], infos[i], dbgs[i], PD,
+                                              rerun=imposed_rerun(ocfg, H, W, keys_u8[i], curs_u8[i], True))[0] for i in range(ns))
+            n1 = max(1, min(8, ns))
+            _, _, _, secs_1 = ko.track_pairs(ocfg, keys_u8[:n1], curs_u8[:n1], True, faithful=False, nthreads=1)
+            _, _, _, secs_1f = ko.track_pairs(ocfg, keys_u8[:n1], curs_u8[:n1], True, faithful=True, nthreads=1)
+            cpu = dict(value=round(ns / secs_all, 2), unit="frame-pairs/s", cores=nthr, kind="port",
+                       sample="%d unique pairs of the same 640x480 workload, lean mode, OpenMP over pairs" % ns,
+                       value_1thread=round(n1 / secs_1, 3), value_1thread_reference_faithful=round(n1 / secs_1f, 3),
+                       host_cpus=ncores, gpu_results_match=bool(parity_ok), pairs_compared=ns)
+        bpp = algorithmic_bytes(H, W, PD, PC)
+        bpc = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
+        out = _line("frame-pairs/s (corr-volume + pose solve) at 640x480", "frame-pairs/s", pairs_per_s, world, args, ms_per_step,
+                    "configs[1]: 640x480 mono, ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), polynomial kernel, polar 720x480, Kzz not cached",
+                    bpp, dict(pairs_per_gpu_per_step=B, unique_pairs=U, parallelism="pairs sharded x%d" % world, residual_allreduce=comm),
+                    roofline=_roofline(kernels, B), cpu_baseline=cpu, parity_spot_check=parity_ok,
+                    residual_stats=None if stats is None else [float(v) for v in stats],
+                    kzz_cached_mode=None if pairs_per_s_cached is None else {
+                        "value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": bpc,
+                        "frac_of_8TBps": round(pairs_per_s_cached * bpc / HBM_PEAK, 4),
+                        "note": "same workload with the per-keyframe Kzz cache on (identical outputs); not the headline"},
+                    kernels=kernels)
+        out["path_roofline"]["bytes_per_pair"] = bpp
+    if grp is not None:
+        grp.close()
+    cf.close()
+    return out
+
+
+def workload_sequence(args, N, torch, np, synth, dev, local_rank):
+    """configs[1] as a real sequence: the C++ tracker (MapBuilder tracking subset) with speculative batches; frames between
+    keyframe switches are registered once, the tail after a switch is re-registered."""
+    H, W, PD, PC = 480, 640, 720, 480
+    T = args.frames
+    cv = synth.canvas(4242, H, W)
+    base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
+    seq = np.stack([base[i % 64] for i in range(T)])
+    d_seq = torch.from_numpy(seq).to(dev)
+    win = min(args.batch, 64)
+    cfg = N.default_config()
+
+    def run(nframes, kw=None):
+        flow = N.CorrelationFlow(cfg, H, W, max_batch=win, max_frames=nframes + win + 2, device=local_rank)
+        flow.set_kzz_cache(True)
+        trk = N.Tracker(flow, N.tracker_config())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = []
+        for b0 in range(0, nframes, win):
+            m = min(win, nframes - b0)
+            outs += trk.push_dev(d_seq[b0:b0 + m].data_ptr(), m)
+        dt = time.perf_counter() - t1
+        trk.close(); flow.close()
+        return outs, dt
+    run(min(T, 256))                                            # warm-up (module load, first launches)
+    best = None
+    for _ in range(max(1, args.steps // 10)):
+        outs, dt = run(T)
+        best = dt if best is None else min(best, dt)
+    # property check (size-independent): pushing the frames one by one gives the same decisions as the speculative windows
+    parity = None
+    if args.cpu_sample > 0:
+        ns = min(T, 96)
+        flow = N.CorrelationFlow(cfg, H, W, max_batch=1, max_frames=ns + 3, device=local_rank)
+        flow.set_kzz_cache(True)
+        trk = N.Tracker(flow, N.tracker_config())
+        one = []
+        for i in range(ns):
+            one += trk.push_dev(d_seq[i:i + 1].data_ptr(), 1)
+        trk.close(); flow.close()
+        same = lambda a, b: all(a[k] == b[k] for k in a if k != "slot")          # (slot numbers depend on the window size)
+        parity = all(same(one[i], outs[i]) for i in range(ns))
+    nkey = int(sum(o["inserted"] for o in outs))
+    bpf = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
+    return _line("frames/s through the tracker (configs[1] as a sequence)", "frames/s", T / best, 1, args, 1e3 * best,
+                 "configs[1] sequence: %d frames, C++ tracker (keyframe rule, PSR gating), speculative windows of %d, Kzz cached per keyframe" % (T, win),
+                 bpf, dict(frames=T, window=win, keyframes=nkey, good_tracking=int(sum(o["good_tracking"] for o in outs))),
+                 parity_spot_check=parity, roofline=None, cpu_baseline=None,
+                 note="latency-bound: every keyframe switch is a dependent round trip of a small batch")
+
+
+def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
+    H, W, B, LEVELS, R = 480, 640, min(args.batch, 32), 4, 4
+    pyr = N.Pyramid(N.default_config(), H, W, levels=LEVELS, max_batch=B, device=local_rank)
+    keys, curs, _ = synth.make_unique_batch(B, H, W, seed0=50, max_theta=8.0, max_shift=40)
+    dk = torch.from_numpy(keys).to(dev); dc = torch.from_numpy(curs).to(dev)
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        res = pyr.track_dev(dk.data_ptr(), dc.data_ptr(), B, R)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = pyr.track_dev(dk.data_ptr(), dc.data_ptr(), B, R)
+    dt = (time.perf_counter() - t0) / args.steps
+    parity = None
+    if args.cpu_sample > 0:
+        from oracle import kcc_oracle as ko
+        ns = min(4, B)
+        poses, _, _, _ = ko.track_pairs(ko.default_config(), keys[:ns], curs[:ns], True, nthreads=ns)
+        parity = all(res[0][i]["pose"][0] == poses[i][0] and res[0][i]["pose"][1] == poses[i][1] for i in range(ns))   # level 0 == plain KCC
+    # per pair: key AND current intermedium plus one pose at every level
+    bpp = sum(intermedium_bytes(h, w, pd, pc) + algorithmic_bytes(h, w, pd, pc) for (h, w, pd, pc) in pyr.dims)
+    out = _line("frame-pairs/s, 4-level pyramid with radius-4 lookup (configs[2])", "frame-pairs/s", B / dt, 1, args, 1e3 * dt,
+                "configs[2]: 640x480 'stereo' (independent mono streams) + 4-level coarse-to-fine, radius-4 windows, batch %d; extension, no reference counterpart" % B,
+                bpp, dict(pairs_per_step=B, levels=pyr.dims), parity_spot_check=parity, roofline=None, cpu_baseline=None)
+    pyr.close()
+    return out
+
+
+def workload_hd(args, N, torch, np, synth, dev, local_rank):
+    H, W, PD, PC = 720, 1280, 720, 480
+    B = min(args.batch, 128)
+    cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=B, max_frames=2 * B, device=local_rank)
+    U = min(B, 16)
+    keys, curs, _ = synth.make_unique_batch(U, H, W, seed0=11, max_theta=8.0, max_shift=60, ncanvas=8)
+    rep = (B + U - 1) // U
+    dk = torch.from_numpy(np.repeat(np.tile(keys, (rep, 1, 1))[:B, :, :, None], 3, axis=3).copy()).to(dev)
+    dc = torch.from_numpy(np.repeat(np.tile(curs, (rep, 1, 1))[:B, :, :, None], 3, axis=3).copy()).to(dev)
+    gk = torch.empty((B, H, W), dtype=torch.uint8, device=dev); gc = torch.empty_like(gk)
+    torch.cuda.synchronize()
+    cf.rgb_to_gray_dev(dk.data_ptr(), B, gk.data_ptr())
+    cf.intermedium_batch_dev(gk.data_ptr(), B, list(range(B))); cf.synchronize()
+    ring = [(N.NikPoseResult * B)() for _ in range(3)]
+
+    def step(k):
+        cf.rgb_to_gray_dev(dc.data_ptr(), B, gc.data_ptr())          # colour conversion is part of the step
+        return cf.track_batch_dev(gc.data_ptr(), list(range(B)), list(range(B, 2 * B)), True, sync=False, res=ring[k % 3])
+    for k in range(args.warmup):
+        step(k)
+    cf.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        res = step(k)
+    cf.synchronize(); torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    parity = None
+    if args.cpu_sample > 0:
+        from kcc_helpers import check_pose_parity
+        from oracle import kcc_oracle as ko
+        ns = min(4, U)
+        poses, infos, dbgs, _ = ko.track_pairs(ko.default_config(), keys[:ns], curs[:ns], True, nthreads=ns)
+        parity = all(check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], PD)[0] for i in range(ns))
+    kernels = [] if args.no_profile else _profile(cf, lambda: cf.track_batch_dev(gc.data_ptr(), list(range(B)), list(range(B, 2 * B)), True, sync=True), 3)
+    out = _line("frame-pairs/s at 1280x720 RGB (configs[3] geometry, one GPU)", "frame-pairs/s", B / dt, 1, args, 1e3 * dt,
+                "configs[3] on one GPU: 1280x720 RGB -> integer luma -> ComputeIntermedium + ComputePose, %d pairs per step (its 8-GPU shard runs the pairs workload's multi-rank code path)" % B,
+                algorithmic_bytes(H, W, PD, PC), dict(pairs_per_step=B, unique_pairs=U), parity_spot_check=parity,
+                roofline=_roofline(kernels, -1), cpu_baseline=None, kernels=kernels)
+    cf.close()
+    return out
+
+
+def workload_loop(args, N, torch, np, synth, dev, local_rank):
+    H, W, PD, PC = 480, 640, 720, 480
+    NC, MB = args.candidates, 128
+    cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=MB, max_frames=NC + 1, device=local_rank)
+    cv = [synth.canvas(900 + i, H, W) for i in range(8)]
+    U = 64
+    uniq = np.stack([synth.window(cv[i % 8], H, W, (7 * i) % 120 - 60, (5 * i) % 160 - 80, 0.5 * (i % 11)) for i in range(U)])
+    d = torch.from_numpy(np.tile(uniq, (MB // U, 1, 1))).to(dev); torch.cuda.synchronize()
+    for b in range(0, NC, MB):
+        m = min(MB, NC - b)
+        cf.intermedium_batch_dev(d.data_ptr(), m, list(range(b, b + m)))
+    true_idx = 44                                                   # (rotation 0: 44 % 11 == 0) candidates i with i % 64 == 44 hold the query's place
+    q = synth.window(cv[true_idx % 8], H, W, (7 * true_idx) % 120 - 60 + 3, (5 * true_idx) % 160 - 80 - 4, 0.0)
+    cf.intermedium_u8(q, NC)
+    cf.synchronize()
+    for _ in range(max(1, args.warmup // 2)):
+        best, res, br = cf.match(NC, list(range(NC)))
+    reps = max(1, args.steps // 5)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        best, res, br = cf.match(NC, list(range(NC)))
+    dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        b2, r2, short = cf.match_topk(NC, list(range(NC)), 16)
+    dt2 = (time.perf_counter() - t0) / reps
+    # size-independent properties at the full size: the winner is the first copy of the true place; every copy of a place scores
+    # the same; the short-list search finds the same score
+    scores = np.array([sum(r["info"]) for r in res])
+    prop = bool(best == true_idx and (br["pose"][0], br["pose"][1]) == (-4, 3) and all(np.all(scores[k::U] == scores[k]) for k in range(U))
+                and abs(sum(r2["info"]) - sum(br["info"])) < 1e-9 and int(scores.argmax()) == best)
+    bpc = algorithmic_bytes(H, W, PD, PC, hypotheses=2, with_intermedium=False)
+    out = _line("loop-closure candidates/s, exact two-hypothesis ComputePose over resident key frames (configs[4])", "candidates/s", NC / dt, 1, args, 1e3 * dt,
+                "configs[4]: 1 query x %d resident key frames (%.1f GB of spectra), not_large_rotation=false on every candidate, strict-> winner" % (NC, NC * 2.62e6 / 1e9),
+                bpc, dict(candidates=NC, chunk=MB), parity_spot_check=prop, roofline=None, cpu_baseline=None,
+                topk16={"candidates_per_s": round(NC / dt2, 1), "ms_per_query": round(1e3 * dt2, 3), "same_best_score": bool(abs(sum(r2["info"]) - sum(br["info"])) < 1e-9),
+                        "note": "extension: rank by rotation-stage PSR, full ComputePose on the top 16"})
+    cf.close()
+    return out
 
 
 def main():
@@ -30,22 +417,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="pairs", choices=["pairs", "sequence", "pyramid", "hd", "loop4096"])
     ap.add_argument("--batch", type=int, default=256, help="frame pairs per GPU per step")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated (tiled to --batch)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic pairs generated (tiled to --batch); 0 = all of them")
     ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
+    ap.add_argument("--frames", type=int, default=2048, help="sequence workload: frames")
+    ap.add_argument("--candidates", type=int, default=4096, help="loop4096 workload: resident key frames")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")
-    ap.add_argument("--sequence", type=int, default=0, help="also report the tracker on a synthetic sequence of this many "
-                    "frames (extra key `sequence`; not the headline metric)")
     args = ap.parse_args()
 
     import numpy as np
     import torch
     import torch.distributed as dist
     import synth
-    from kcc_helpers import PKG, check_pose_parity, load_module, nik
+    from kcc_helpers import nik
     N = nik()
-    kd = load_module("kcc_dist", os.path.join(PKG, "kcc_dist.py"))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -64,175 +451,20 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    B, U = args.batch, min(args.unique, args.batch)
-    keys_u8, curs_u8, motions = synth.make_batch(U, H, W, seed0=1000 * rank, max_shift=48, max_theta=10.0)
-    reps = (B + U - 1) // U
-    keys_b = np.tile(keys_u8, (reps, 1, 1))[:B]
-    curs_b = np.tile(curs_u8, (reps, 1, 1))[:B]
-    d_keys = torch.from_numpy(keys_b).to(dev)
-    d_curs = torch.from_numpy(curs_b).to(dev)
-    torch.cuda.synchronize()
-
-    cfg = N.default_config()
-    cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
-    key_slots = list(range(B))
-    cur_slots = list(range(B, 2 * B))
-    cf.intermedium_batch_dev(d_keys.data_ptr(), B, key_slots)       # keyframe spectra: prepared before the timed region
-    cf.synchronize()
-    stats = torch.zeros(4, dtype=torch.float64, device=dev)
-
-    # The library keeps two calls in flight per stream; results of step k are final once step k+2 has been queued
-    # (or after synchronize()).  The per-step residual all-reduce therefore carries the statistics of step k-2.
-    ring = [(N.NikPoseResult * B)() for _ in range(3)]
-    state = {"k": 0}
-
-    def step():
-        k = state["k"]
-        res = cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=False, res=ring[k % 3])
-        if world > 1 and k >= 2:
-            stats.copy_(kd.residual_stats(ring[(k - 2) % 3]), non_blocking=True)
-            kd.allreduce_residual_stats(stats)                       # RCCL: [sum PSR_t, sum PSR_r, sum |t|^2, count]
-        state["k"] = k + 1
-        return res
-
-    for _ in range(args.warmup):
-        res = step()
-    cf.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    cf.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    pairs_per_s = B * world / (dt / args.steps)
-
-    # extra (not the headline): the same workload with the per-keyframe Kzz cache (SURVEY 8d "Kzz cached", 30.17 MB/pair)
-    pairs_per_s_cached = None
-    if not args.no_cached:
-        cf.set_kzz_cache(True)
-        for _ in range(2):
-            step()
-        cf.synchronize()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        cf.synchronize()
-        torch.cuda.synchronize()
-        pairs_per_s_cached = B / ((time.perf_counter() - t1) / args.steps)       # this rank only
-        cf.set_kzz_cache(False)
-
-    out = None
-    if rank == 0:
-        # ---- per-kernel roofline: HIP events around every launch, on the launch stream, over extra timed steps
-        roof = None
-        kernels = []
-        if not args.no_profile:
-            nstreams = cf.set_streams(1)         # per-kernel durations are only meaningful without co-running kernels
-            cf.profile_enable(True)
-            psteps = max(2, min(args.steps, 5))
-            for _ in range(psteps):
-                cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=True)
-            st = cf.profile_read()
-            cf.profile_enable(False)
-            cf.set_streams(int(os.environ.get("NIK_STREAMS", "2")))
-            tot = sum(s["ms"] for s in st)
-            for s in sorted(st, key=lambda s: -s["ms"]):
-                avg_ms = s["ms"] / s["launches"]
-                bpl = s["bytes"] / s["launches"]
-                kernels.append(dict(name=s["name"], avg_ms=round(avg_ms, 4), share=round(s["ms"] / tot, 4),
-                                    bytes_per_launch=bpl, gbps=round(bpl / (avg_ms * 1e-3) / 1e9, 1)))
-            top = kernels[0]
-            ach = top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9
-            # measured HBM bytes of that kernel per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as
-            # DESIGN.md section 4 describes; committed summary) -- only valid for the batch size it was collected at
-            traffic = None
-            try:
-                import glob
-                pm = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]))
-                if pm.get("pairs_per_launch") == B:
-                    traffic = pm["traffic_bytes_per_launch"].get(top["name"])
-            except Exception:
-                traffic = None
-            roof = dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s",
-                        frac=round(ach / (HBM_PEAK / 1e9), 4), traffic=traffic, avg_ms=top["avg_ms"],
-                        bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
-        # ---- CPU baseline: the oracle (a dependency-free port; the reference itself is unbuildable here).  This leg is
-        # the only place bench.py touches oracle/; its per-pair outputs double as a parity spot check of the last step.
-        cpu = None
-        parity_ok = None
-        if args.cpu_sample > 0:
-            from oracle import kcc_oracle as ko
-            ocfg = ko.default_config()
-            ncores = os.cpu_count() or 1
-            ns = args.cpu_sample
-            reps_c = (ns + U - 1) // U
-            kk, cc = np.tile(keys_u8, (reps_c, 1, 1))[:ns], np.tile(curs_u8, (reps_c, 1, 1))[:ns]
-            # the oracle allocates plane-sized temporaries per call (like the reference's Eigen temporaries); on the
-            # 2x64-core host its throughput peaks near 32 threads (tools/cpu_scale.py), so that is what is reported
-            nthr = min(ncores, ns, 32)
-            poses, infos, dbgs, secs_all = ko.track_pairs(ocfg, kk, cc, True, faithful=False, nthreads=nthr)
-            ncheck = min(ns, B)                                          # sample pair i == pair i of the batch
-            parity_ok = all(check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], PD)[0] for i in range(ncheck))
-            n1 = max(1, min(8, ns))
-            _, _, _, secs_1 = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=False, nthreads=1)
-            _, _, _, secs_1f = ko.track_pairs(ocfg, kk[:n1], cc[:n1], True, faithful=True, nthreads=1)
-            cpu = dict(value=round(ns / secs_all, 2), unit="frame-pairs/s", cores=nthr, kind="port",
-                       sample="%d pairs of the same 640x480 workload, lean mode, OpenMP over pairs" % ns,
-                       value_1thread=round(n1 / secs_1, 3), value_1thread_reference_faithful=round(n1 / secs_1f, 3),
-                       host_cpus=ncores, gpu_results_match=bool(parity_ok), pairs_compared=ncheck)
-        out = {
-            "metric": "frame-pairs/s (corr-volume + pose solve) at 640x480", "value": round(pairs_per_s, 1),
-            "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: 640x480 mono, ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), "
-                                   "polynomial kernel, polar 720x480, Kzz not cached",
-                       "pairs_per_gpu_per_step": B, "unique_pairs": U, "parallelism": "pairs sharded x%d" % world,
-                       "streams_per_gpu": int(os.environ.get("NIK_STREAMS", "2"))},
-            "path_roofline": {"bytes_per_pair": BYTES_PER_PAIR, "achieved_GBps": round(pairs_per_s / world * BYTES_PER_PAIR / 1e9, 1),
-                              "frac_of_8TBps": round(pairs_per_s / world * BYTES_PER_PAIR / HBM_PEAK, 4)},
-            "roofline": roof, "cpu_baseline": cpu, "parity_spot_check": parity_ok,
-            "kzz_cached_mode": None if pairs_per_s_cached is None else {
-                "value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": 30.17e6,
-                "frac_of_8TBps": round(pairs_per_s_cached * 30.17e6 / HBM_PEAK, 4),
-                "note": "same workload with the per-keyframe Kzz cache on (identical outputs); not the headline"},
-            "kernels": kernels,
-        }
-        if args.sequence > 0:
-            # configs[1] as a real sequence: the C++ tracker (MapBuilder tracking subset) with speculative batches;
-            # frames between keyframe switches are registered once, the tail after a switch is re-registered.
-            cv = synth.canvas(4242, H, W)
-            base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
-            seq = np.stack([base[i % 64] for i in range(args.sequence)])
-            d_seq = torch.from_numpy(seq).to(dev)
-            win = min(B, 64)
-            flow2 = N.CorrelationFlow(cfg, H, W, max_batch=win, max_frames=args.sequence + win + 2, device=local_rank)
-            flow2.set_kzz_cache(True)
-            trk = N.Tracker(flow2, N.tracker_config())
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            outs = []
-            for b0 in range(0, args.sequence, win):
-                m = min(win, args.sequence - b0)
-                outs += trk.push_dev(d_seq[b0:b0 + m].data_ptr(), m)
-            dt_seq = time.perf_counter() - t1
-            out["sequence"] = {"frames": args.sequence, "window": win, "frames_per_s": round(args.sequence / dt_seq, 1),
-                               "keyframes": int(sum(o["inserted"] for o in outs)),
-                               "good_tracking": int(sum(o["good_tracking"] for o in outs))}
-            trk.close(); flow2.close()
+    if args.workload == "pairs":
+        out = workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank)
+    elif world > 1:
+        raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
+    elif args.workload == "sequence":
+        out = workload_sequence(args, N, torch, np, synth, dev, local_rank)
+    elif args.workload == "pyramid":
+        out = workload_pyramid(args, N, torch, np, synth, dev, local_rank)
+    elif args.workload == "hd":
+        out = workload_hd(args, N, torch, np, synth, dev, local_rank)
+    else:
+        out = workload_loop(args, N, torch, np, synth, dev, local_rank)
+    if rank == 0 and out is not None:
         print(json.dumps(out))
-    cf.close()
     if world > 1:
         dist.destroy_process_group()
 

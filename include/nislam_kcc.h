@@ -82,6 +82,8 @@ const char* nik_last_error(const nik_ctx* ctx);      /* ctx may be NULL: last cr
 int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
 /* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
+int   nik_device(const nik_ctx* ctx);                        /* HIP device ordinal the context lives on */
+int   nik_device(const nik_ctx* ctx);
 /* A batched call is split over up to `n` concurrent HIP streams ("lanes", default 2 or $NIK_STREAMS, max 4);
  * returns the number now active.  Outputs do not depend on it. */
 int  nik_set_streams(nik_ctx* ctx, int n);
@@ -318,6 +320,53 @@ typedef struct {
 } nik_stage_stat;
 int nik_profile_enable(nik_ctx* ctx, int enable);
 int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);
+
+/* ---- residual statistics of a batch, reduced on the device --------------------------------------
+ * stats = [sum PSR_t (chosen hypothesis), sum PSR_r, sum |t|^2 (px^2), count] over the pairs of the latest
+ * nik_pose_batch / nik_track_batch_dev / nik_match call: the per-batch "residual sum" that a multi-GPU run all-reduces
+ * (nik_group_allreduce_residual).  Off by default; when on, every batch call appends one tiny reduction kernel per stream. */
+int nik_set_residual_stats(nik_ctx* ctx, int enable);
+/* device pointer to the 4 doubles of the latest batch, valid in stream order on *stream (a hipStream_t owned by the
+ * context; asynchronous: nothing is waited for).  Work enqueued on that stream delays nothing but the next batch's own
+ * statistics. */
+int nik_residual_stats_dev(nik_ctx* ctx, double** d_stats4, void** stream);
+/* the same on the host (waits for the batch) */
+int nik_residual_stats(nik_ctx* ctx, double stats[4]);
+
+/* ---- multi-GPU: nik_group (kcc_group.cpp) ----------------------------------------------------
+ * The path shards by independent units (frame pairs; loop-closure candidates), so a group is a set of contexts, one per
+ * GPU, plus an RCCL communicator for the two small exchanges: the all-reduce of the per-batch residual statistics and
+ * the all-gather of each GPU's best loop-closure candidate (reference src/loop_closure.cc:61-65).
+ *   one process, every GPU of the node : nik_group_create_local  (a C++ MapBuilder linking this library)
+ *   one process per GPU                : nik_group_unique_id on rank 0, broadcast by the launcher, nik_group_create_rank
+ * RCCL is loaded on first use (dlopen librccl.so.1); groups of one GPU need no RCCL at all. */
+typedef struct nik_group nik_group;
+#define NIK_GROUP_ID_BYTES 128
+const char* nik_group_last_error(const nik_group* g);          /* g may be NULL: the last create error of this thread */
+int  nik_group_unique_id(uint8_t id[NIK_GROUP_ID_BYTES]);
+int  nik_group_create_rank(nik_ctx* ctx, int rank, int world, const uint8_t id[NIK_GROUP_ID_BYTES], nik_group** out);   /* borrows ctx */
+int  nik_group_create_local(const nik_config* cfg, int image_height, int image_width, int max_batch, int max_frames,
+                            int n_devices, const int* devices /* NULL: 0..n-1 */, nik_group** out);                    /* owns its contexts */
+void nik_group_destroy(nik_group* g);
+int  nik_group_world(const nik_group* g);                      /* GPUs in the group */
+int  nik_group_local_count(const nik_group* g);                /* members driven by this process (world, or 1) */
+nik_ctx* nik_group_ctx(nik_group* g, int local_index);
+int  nik_group_rank(const nik_group* g, int local_index);
+/* contiguous shard [begin, end) of n units for `rank` of `world` (sizes differ by at most one; rank order = unit order) */
+void nik_group_shard(int n, int world, int rank, int* begin, int* end);
+/* sum over the group of every member's latest-batch statistics (nik_set_residual_stats is switched on by the group),
+ * reduced on the devices and all-reduced with RCCL; asynchronous when out == NULL (fetch with nik_group_residual_result) */
+int  nik_group_allreduce_residual(nik_group* g, double out[4]);
+int  nik_group_residual_result(nik_group* g, double out[4]);
+/* every local member's best candidate (global index, -1: none) -> the group's winner by the reference's rule */
+int  nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_result* local_best, int* best_index, nik_pose_result* best);
+/* local groups: a batch of n pairs (host u8 images) sharded over the GPUs; keys[i] / cur_dst[i] are slots of the member
+ * that owns pair i (nik_group_shard) */
+int  nik_group_track_batch(nik_group* g, int n, const uint8_t* h_gray, const nik_frame* keys, const nik_frame* cur_dst,
+                           int not_large_rotation, nik_pose_result* res);
+/* local groups: FindLoopClosure's candidate loop over a key-frame store sharded over the GPUs (cands[r]: slots of member r) */
+int  nik_group_match(nik_group* g, const uint8_t* h_query, nik_frame query_slot, const int* n_cands, const nik_frame* const* cands,
+                     int* best_member, int* best_local, nik_pose_result* best);
 
 /* ---- debug / parity taps (used by tests only) --------------------------------------------- */
 

@@ -9,7 +9,7 @@ LIB = os.path.join(HERE, "libnislam_kcc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # -fno-slp-vectorize: packed FP32 (v_pk_*) buys no throughput on gfx950 and costs register shuffles (measured +9 %)
-UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
+UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_group.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
          ("kcc_camera.cpp", ["-ffp-contract=off"]), ("kcc_map.cpp", ["-ffp-contract=off"]),
          ("kcc_posegraph.cpp", ["-ffp-contract=off"]), ("kcc_pyramid.cpp", ["-ffp-contract=off"]),
          ("kcc_stitcher.hip", ["-ffp-contract=off"])]
@@ -38,7 +38,7 @@ def build(force=False, verbose=False, defs=(), suffix=""):
             subprocess.check_call(cmd)
         objs.append(o)
     if force or _stale(lib, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", lib]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-lpthread", "-o", lib]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

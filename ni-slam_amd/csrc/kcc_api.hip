@@ -104,6 +104,10 @@ struct nik_ctx {
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     float* d_scratch = nullptr;          // debug / import-export staging
+    // residual statistics of the latest batch (nik_set_residual_stats): per-lane partials [4 lanes][4] + their sum [4], device
+    // They are summed (and all-reduced, nik_group) on their own stream so that no lane waits for another.
+    bool want_stats = false; double* d_stats = nullptr; double* h_stats = nullptr; int stats_lanes = 0;
+    hipStream_t stats_stream = nullptr; hipEvent_t stats_done = nullptr; bool stats_pending = false;
     PolarPlan polar{};                   // gather tables of the polar forward kernel (device pointers; kcc_tables.cpp)
     int* rot_one = nullptr;              // one-angle de-rotation table (nik_dbg_rotate)
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
@@ -674,7 +678,10 @@ void nik_destroy(nik_ctx* c) {
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
     (void)hipFree(c->arena_u8); (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
     (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
-    (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2);
+    (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2); (void)hipFree(c->d_stats);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->stats_stream) { (void)hipStreamSynchronize(c->stats_stream); (void)hipStreamDestroy(c->stats_stream); }
+    if (c->stats_done) (void)hipEventDestroy(c->stats_done);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(const_cast<uint32_t*>(c->polar.chunks)); (void)hipFree(const_cast<int*>(c->polar.seg_first));
     (void)hipFree(const_cast<uint4*>(c->polar.pts)); (void)hipFree(c->rot_tab); (void)hipFree(c->rot_one);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -689,6 +696,7 @@ int nik_get_dims(const nik_ctx* c, int dims[6]) {
     dims[0] = c->H; dims[1] = c->W; dims[2] = c->PD; dims[3] = c->PC; dims[4] = c->max_batch; dims[5] = c->max_frames;
     return NIK_OK;
 }
+int nik_device(const nik_ctx* c) { return c ? c->device : -1; }
 void* nik_stream(const nik_ctx* c) { return c ? (void*)c->lanes[0].stream : nullptr; }
 
 int nik_set_streams(nik_ctx* c, int n) {
@@ -697,6 +705,46 @@ int nik_set_streams(nik_ctx* c, int n) {
     if (rc) return rc;
     c->active_lanes = std::max(1, std::min((int)c->lanes.size(), n));
     return c->active_lanes;
+}
+
+int nik_set_residual_stats(nik_ctx* c, int enable) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    if (enable && !c->d_stats) {
+        HIP_TRY(c, hipMalloc(&c->d_stats, sizeof(double) * 4 * 5));           // 4 lane partials + the total
+        HIP_TRY(c, hipMemset(c->d_stats, 0, sizeof(double) * 4 * 5));
+        HIP_TRY(c, hipHostMalloc(&c->h_stats, sizeof(double) * 4));
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->stats_stream, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->stats_done, hipEventDisableTiming));
+    }
+    c->want_stats = enable != 0; c->stats_lanes = 0;
+    return NIK_OK;
+}
+
+// total of the latest batch call's per-lane partials, enqueued on the statistics stream behind every lane's share
+int nik_residual_stats_dev(nik_ctx* c, double** d_total, void** stream) {
+    if (!c || !d_total) return NIK_ERR_INVALID_ARG;
+    if (!c->want_stats) return fail(c, NIK_ERR_NOT_READY, "residual statistics are off (nik_set_residual_stats)");
+    for (int li = 0; li < c->stats_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->stats_stream, c->lanes[li].tail_ev, 0));
+    launch_stats_sum(c->stats_stream, c->d_stats, c->stats_lanes, c->d_stats + 16);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->stats_done, c->stats_stream));
+    c->stats_pending = true;
+    *d_total = c->d_stats + 16;
+    if (stream) *stream = (void*)c->stats_stream;
+    return NIK_OK;
+}
+
+int nik_residual_stats(nik_ctx* c, double out[4]) {
+    if (!c || !out) return NIK_ERR_INVALID_ARG;
+    double* d = nullptr;
+    int rc = nik_residual_stats_dev(c, &d, nullptr);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->h_stats, d, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stats_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stats_stream));
+    memcpy(out, c->h_stats, sizeof(double) * 4);
+    return NIK_OK;
 }
 
 int nik_set_kzz_cache(nik_ctx* c, int enable) {
@@ -909,6 +957,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
+    c->stats_lanes = 0;
     for (int li = 0; li < nl; ++li) {
         int b, e; chunk_of(n, nl, li, b, e);
         const int m = e - b; if (m <= 0) continue;
@@ -945,6 +994,11 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             if (!img_u8 && (rc = ensure_f32_images(c, L, li, m, curs + b))) return rc;
         }
         if ((rc = enqueue_pose(c, L, m, not_large_rotation, img_u8, fuse, win_centers ? win_radius : -1))) return rc;
+        if (c->want_stats) {                                  // this lane's share of the batch's residual statistics
+            if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0));   // (the previous batch's partials are consumed)
+            launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, not_large_rotation ? 1 : 2, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
+            c->stats_lanes = std::max(c->stats_lanes, li + 1);
+        }
         if (fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;

@@ -1,0 +1,378 @@
+// kcc_group.cpp -- multi-GPU entry points of the C ABI (include/nislam_kcc.h "nik_group").
+//
+// The KCC front end shards by independent units: frame pairs for tracking, candidate key frames for loop
+// closure (reference loop: src/loop_closure.cc:36-73; the CorrelationFlow object MapBuilder and LoopClosure share:
+// src/map_builder.cc:23-26).  No data moves between GPUs on the data path.  The two exchanges are
+//   * one RCCL all-reduce of 4 doubles per batch -- [sum PSR_t, sum PSR_r, sum |t|^2, count], reduced on each device from
+//     the raw surface results (nik_residual_stats_dev) and summed over the GPUs (xGMI);
+//   * one RCCL all-gather of each GPU's best loop-closure candidate (8 doubles) followed by the reference's selection rule
+//     (loop_closure.cc:61-65: a strictly larger response.sum() wins, so the first candidate in global order wins ties).
+// Two deployments share the code: one process driving every GPU of the node (nik_group_create_local: what a C++ MapBuilder
+// linking this library uses), and one process per GPU (nik_group_create_rank: torchrun / MPI style launchers).
+//
+// RCCL is loaded at run time (dlopen "librccl.so.1"): the core library keeps working where RCCL is absent, and a host
+// process that already carries an RCCL (e.g. PyTorch's) shares it instead of loading a second copy.
+#include "../../include/nislam_kcc.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and enums only; every function is resolved with dlsym
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static bool tried = false;
+    if (tried) return r;
+    tried = true;
+    for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);          // reuse a copy the host process already loaded
+        if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) { r.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "librccl.so.1"); return r; }
+#define SYM(field, sym) do { *(void**)(&r.field) = dlsym(r.lib, sym); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; return r; } } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
+    SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    r.ok = true;
+    return r;
+}
+
+thread_local std::string g_group_error;
+
+struct Member {                 // one GPU of this process
+    nik_ctx* ctx = nullptr;
+    int device = 0, rank = 0;
+    ncclComm_t comm = nullptr;
+    double* d_buf = nullptr;    // [4] all-reduced statistics | [8] my best record | [8 * world] gathered records
+    double* h_buf = nullptr;    // pinned mirror
+    hipStream_t stream = nullptr;   // the context's statistics stream once statistics were requested, else a private one
+    hipStream_t own_stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t* d_stage = nullptr; size_t stage_cap = 0;      // upload staging of nik_group_track_batch
+    std::string err;            // error of this member's share of a fan-out call
+};
+
+// run f(member index) for every local member concurrently (one host thread per GPU; member 0 on the caller's thread)
+template <class F> void for_each_member(size_t n, F f) {
+    std::vector<std::thread> th;
+    for (size_t r = 1; r < n; ++r) th.emplace_back([&f, r] { f(r); });
+    f(0);
+    for (std::thread& t : th) t.join();
+}
+
+}  // namespace
+
+struct nik_group {
+    int world = 1;
+    bool use_rccl = false;      // world > 1, or $NIK_GROUP_FORCE_RCCL (tests: the RCCL calls with a single rank)
+    bool owns_ctx = false;
+    std::vector<Member> m;      // local members (world of them in a local group, one in a rank group)
+    std::string err;
+    bool stats_inflight = false;
+};
+
+namespace {
+
+int gfail(nik_group* g, int code, const std::string& msg) {
+    if (g) g->err = msg; else g_group_error = msg;
+    return code;
+}
+#define G_HIP(g, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return gfail(g, NIK_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define G_NCCL(g, expr) do { ncclResult_t r_ = (expr); if (r_ != ncclSuccess) return gfail(g, NIK_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(r_)); } while (0)
+
+int member_init(nik_group* g, Member& mb) {
+    G_HIP(g, hipSetDevice(mb.device));
+    G_HIP(g, hipMalloc(&mb.d_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world)));
+    G_HIP(g, hipHostMalloc(&mb.h_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world)));
+    G_HIP(g, hipStreamCreateWithFlags(&mb.own_stream, hipStreamNonBlocking));
+    G_HIP(g, hipEventCreateWithFlags(&mb.done, hipEventDisableTiming));
+    mb.stream = mb.own_stream;
+    int rc = nik_set_residual_stats(mb.ctx, 1);
+    if (rc) return gfail(g, rc, std::string("nik_set_residual_stats: ") + nik_last_error(mb.ctx));
+    return NIK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* nik_group_last_error(const nik_group* g) { return g ? g->err.c_str() : g_group_error.c_str(); }
+
+void nik_group_shard(int n, int world, int rank, int* begin, int* end) {
+    // contiguous shards whose sizes differ by at most one, order preserved (rank order == global unit order)
+    const int base = world > 0 ? n / world : 0, rem = world > 0 ? n % world : 0;
+    const int b = rank * base + std::min(rank, rem);
+    if (begin) *begin = b;
+    if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
+
+int nik_group_unique_id(uint8_t id[NIK_GROUP_ID_BYTES]) {
+    if (!id) return NIK_ERR_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) <= NIK_GROUP_ID_BYTES, "unique id does not fit");
+    if (!rccl().ok) return gfail(nullptr, NIK_ERR_HIP, rccl().err);
+    ncclUniqueId u;
+    G_NCCL(nullptr, rccl().GetUniqueId(&u));
+    memset(id, 0, NIK_GROUP_ID_BYTES);
+    memcpy(id, &u, sizeof(u));
+    return NIK_OK;
+}
+
+void nik_group_destroy(nik_group* g) {
+    if (!g) return;
+    for (Member& mb : g->m) {
+        (void)hipSetDevice(mb.device);
+        if (mb.own_stream) (void)hipStreamSynchronize(mb.own_stream);
+        if (mb.ctx) (void)nik_synchronize(mb.ctx);
+        if (mb.comm && rccl().ok) (void)rccl().CommDestroy(mb.comm);
+        if (mb.done) (void)hipEventDestroy(mb.done);
+        if (mb.own_stream) (void)hipStreamDestroy(mb.own_stream);
+        (void)hipFree(mb.d_buf); (void)hipFree(mb.d_stage);
+        if (mb.h_buf) (void)hipHostFree(mb.h_buf);
+        if (g->owns_ctx && mb.ctx) nik_destroy(mb.ctx);
+    }
+    delete g;
+}
+
+int nik_group_create_rank(nik_ctx* ctx, int rank, int world, const uint8_t id[NIK_GROUP_ID_BYTES], nik_group** out) {
+    if (!ctx || !out || world <= 0 || rank < 0 || rank >= world || (world > 1 && !id)) return gfail(nullptr, NIK_ERR_INVALID_ARG, "bad argument");
+    *out = nullptr;
+    nik_group* g = new nik_group();
+    g->world = world; g->owns_ctx = false;
+    g->m.resize(1);
+    Member& mb = g->m[0];
+    mb.ctx = ctx; mb.rank = rank;
+    mb.device = nik_device(ctx);
+    int rc = member_init(g, mb);
+    g->use_rccl = world > 1 || getenv("NIK_GROUP_FORCE_RCCL") != nullptr;
+    if (!rc && g->use_rccl) {
+        if (!rccl().ok) rc = gfail(g, NIK_ERR_HIP, rccl().err);
+        else {
+            ncclUniqueId u;
+            if (id) memcpy(&u, id, sizeof(u));
+            else if (rccl().GetUniqueId(&u) != ncclSuccess) memset(&u, 0, sizeof(u));
+            ncclResult_t r = rccl().CommInitRank(&mb.comm, world, u, rank);
+            if (r != ncclSuccess) rc = gfail(g, NIK_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+        }
+    }
+    if (rc) { g_group_error = g->err; nik_group_destroy(g); return rc; }
+    *out = g;
+    return NIK_OK;
+}
+
+int nik_group_create_local(const nik_config* cfg, int image_height, int image_width, int max_batch, int max_frames,
+                           int n_devices, const int* devices, nik_group** out) {
+    if (!cfg || !out || n_devices <= 0) return gfail(nullptr, NIK_ERR_INVALID_ARG, "bad argument");
+    *out = nullptr;
+    nik_group* g = new nik_group();
+    g->world = n_devices; g->owns_ctx = true;
+    g->m.resize(n_devices);
+    int rc = NIK_OK;
+    std::vector<int> devs(n_devices);
+    for (int i = 0; i < n_devices && !rc; ++i) {
+        Member& mb = g->m[i];
+        mb.rank = i; mb.device = devs[i] = devices ? devices[i] : i;
+        rc = nik_create(cfg, image_height, image_width, max_batch, max_frames, mb.device, &mb.ctx);
+        if (rc) { gfail(g, rc, std::string("nik_create on device ") + std::to_string(mb.device) + ": " + nik_last_error(nullptr)); break; }
+        rc = member_init(g, mb);
+    }
+    g->use_rccl = n_devices > 1 || getenv("NIK_GROUP_FORCE_RCCL") != nullptr;
+    if (!rc && g->use_rccl) {
+        if (!rccl().ok) rc = gfail(g, NIK_ERR_HIP, rccl().err);
+        else {
+            std::vector<ncclComm_t> comms(n_devices);
+            ncclResult_t r = rccl().CommInitAll(comms.data(), n_devices, devs.data());
+            if (r != ncclSuccess) rc = gfail(g, NIK_ERR_HIP, std::string("ncclCommInitAll: ") + rccl().GetErrorString(r));
+            else for (int i = 0; i < n_devices; ++i) g->m[i].comm = comms[i];
+        }
+    }
+    if (rc) { g_group_error = g->err; nik_group_destroy(g); return rc; }
+    *out = g;
+    return NIK_OK;
+}
+
+int nik_group_world(const nik_group* g) { return g ? g->world : 0; }
+int nik_group_local_count(const nik_group* g) { return g ? (int)g->m.size() : 0; }
+nik_ctx* nik_group_ctx(nik_group* g, int local_index) { return (g && local_index >= 0 && local_index < (int)g->m.size()) ? g->m[local_index].ctx : nullptr; }
+int nik_group_rank(const nik_group* g, int local_index) { return (g && local_index >= 0 && local_index < (int)g->m.size()) ? g->m[local_index].rank : -1; }
+
+// all-reduce of the latest batch's residual statistics: every member's 4 doubles are summed over the whole group, on the
+// devices (each context's statistics stream; RCCL over xGMI between GPUs).  Asynchronous: the result is fetched by
+// nik_group_residual_result (or here when out != NULL).
+int nik_group_allreduce_residual(nik_group* g, double out[4]) {
+    if (!g) return NIK_ERR_INVALID_ARG;
+    const bool multi = g->use_rccl;
+    std::vector<double*> src(g->m.size());
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        G_HIP(g, hipSetDevice(mb.device));
+        void* st = nullptr;
+        int rc = nik_residual_stats_dev(mb.ctx, &src[i], &st);
+        if (rc) return gfail(g, rc, std::string("nik_residual_stats_dev: ") + nik_last_error(mb.ctx));
+        mb.stream = (hipStream_t)st;
+    }
+    if (multi) G_NCCL(g, rccl().GroupStart());
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        G_HIP(g, hipSetDevice(mb.device));
+        if (multi) G_NCCL(g, rccl().AllReduce(src[i], mb.d_buf, 4, ncclDouble, ncclSum, mb.comm, mb.stream));
+        else G_HIP(g, hipMemcpyAsync(mb.d_buf, src[i], sizeof(double) * 4, hipMemcpyDeviceToDevice, mb.stream));
+    }
+    if (multi) G_NCCL(g, rccl().GroupEnd());
+    Member& m0 = g->m[0];
+    G_HIP(g, hipSetDevice(m0.device));
+    G_HIP(g, hipMemcpyAsync(m0.h_buf, m0.d_buf, sizeof(double) * 4, hipMemcpyDeviceToHost, m0.stream));
+    G_HIP(g, hipEventRecord(m0.done, m0.stream));
+    g->stats_inflight = true;
+    return out ? nik_group_residual_result(g, out) : NIK_OK;
+}
+
+int nik_group_residual_result(nik_group* g, double out[4]) {
+    if (!g || !out) return NIK_ERR_INVALID_ARG;
+    if (!g->stats_inflight) return gfail(g, NIK_ERR_NOT_READY, "no all-reduce in flight");
+    G_HIP(g, hipEventSynchronize(g->m[0].done));
+    memcpy(out, g->m[0].h_buf, sizeof(double) * 4);
+    return NIK_OK;
+}
+
+// Loop closure over a sharded candidate set: every member contributes its best candidate (global index, result), the
+// records are all-gathered and the reference's rule picks the winner (loop_closure.cc:61-65; -1: none).
+int nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_result* local_best, int* best_index, nik_pose_result* best) {
+    if (!g || !global_index || !local_best || !best_index) return NIK_ERR_INVALID_ARG;
+    const bool multi = g->use_rccl;
+    const int W8 = 8 * g->world;
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        G_HIP(g, hipSetDevice(mb.device));
+        double* rec = mb.h_buf + 4;
+        if (global_index[i] >= 0) {
+            const nik_pose_result& r = local_best[i];
+            rec[0] = r.info[0] + r.info[1] + r.info[2]; rec[1] = (double)global_index[i];
+            for (int k = 0; k < 3; ++k) { rec[2 + k] = r.pose[k]; rec[5 + k] = r.info[k]; }
+        } else {
+            for (int k = 0; k < 8; ++k) rec[k] = 0.0;
+            rec[1] = -1.0;
+        }
+        G_HIP(g, hipMemcpyAsync(mb.d_buf + 4, rec, sizeof(double) * 8, hipMemcpyHostToDevice, mb.own_stream));
+    }
+    if (multi) G_NCCL(g, rccl().GroupStart());
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        G_HIP(g, hipSetDevice(mb.device));
+        if (multi) G_NCCL(g, rccl().AllGather(mb.d_buf + 4, mb.d_buf + 12, 8, ncclDouble, mb.comm, mb.own_stream));
+        else G_HIP(g, hipMemcpyAsync(mb.d_buf + 12, mb.d_buf + 4, sizeof(double) * 8, hipMemcpyDeviceToDevice, mb.own_stream));
+    }
+    if (multi) G_NCCL(g, rccl().GroupEnd());
+    Member& m0 = g->m[0];
+    G_HIP(g, hipSetDevice(m0.device));
+    G_HIP(g, hipMemcpyAsync(m0.h_buf + 12, m0.d_buf + 12, sizeof(double) * W8, hipMemcpyDeviceToHost, m0.own_stream));
+    for (Member& mb : g->m) { G_HIP(g, hipSetDevice(mb.device)); G_HIP(g, hipStreamSynchronize(mb.own_stream)); }
+    const double* all = m0.h_buf + 12;
+    int bi = -1; double bs = -3.0;                                   // LoopClosureResult(): response(-1,-1,-1)  (loop_closure.h:14)
+    for (int r = 0; r < g->world; ++r)                               // rank order == global candidate order (contiguous shards)
+        if (all[8 * r + 1] >= 0 && all[8 * r] > bs) { bs = all[8 * r]; bi = r; }
+    *best_index = bi >= 0 ? (int)all[8 * bi + 1] : -1;
+    if (best && bi >= 0) {
+        memset(best, 0, sizeof(*best));
+        for (int k = 0; k < 3; ++k) { best->pose[k] = all[8 * bi + 2 + k]; best->info[k] = all[8 * bi + 5 + k]; }
+        // (the arg-max details of the winner stay with the member that owns it; a member whose own record won returns it whole)
+        for (size_t i = 0; i < g->m.size(); ++i) if (global_index[i] == *best_index) *best = local_best[i];
+    }
+    return NIK_OK;
+}
+
+// ---- one process, every GPU: sharded batches ---------------------------------------------------------------
+
+// n frame pairs (host u8 images, h_gray[n][H*W]) registered against resident key frames; pair i runs on member
+// r = shard(i) with keys[i] / cur_dst[i] naming slots of THAT member's context.  The uploads and the kernels of the
+// members overlap; res[n] is complete on return.
+int nik_group_track_batch(nik_group* g, int n, const uint8_t* h_gray, const nik_frame* keys, const nik_frame* cur_dst,
+                          int not_large_rotation, nik_pose_result* res) {
+    if (!g || !h_gray || !keys || !cur_dst || !res || n < 0) return NIK_ERR_INVALID_ARG;
+    if (g->m.size() != (size_t)g->world) return gfail(g, NIK_ERR_INVALID_ARG, "nik_group_track_batch needs a local group");
+    int dims[6];
+    nik_get_dims(g->m[0].ctx, dims);
+    const size_t N = (size_t)dims[0] * dims[1];
+    std::vector<int> rcs(g->m.size(), NIK_OK);
+    for_each_member(g->m.size(), [&](size_t r) {
+        int b, e; nik_group_shard(n, g->world, (int)r, &b, &e);
+        if (e <= b) return;
+        Member& mb = g->m[r];
+        const size_t bytes = N * (size_t)(e - b);
+        hipError_t he = hipSetDevice(mb.device);
+        if (he == hipSuccess && bytes > mb.stage_cap) {
+            (void)hipFree(mb.d_stage); mb.d_stage = nullptr; mb.stage_cap = 0;
+            he = hipMalloc(&mb.d_stage, bytes);
+            if (he == hipSuccess) mb.stage_cap = bytes;
+        }
+        if (he == hipSuccess) he = hipMemcpy(mb.d_stage, h_gray + N * (size_t)b, bytes, hipMemcpyHostToDevice);
+        if (he != hipSuccess) { mb.err = hipGetErrorString(he); rcs[r] = NIK_ERR_HIP; return; }
+        rcs[r] = nik_track_batch_dev(mb.ctx, e - b, mb.d_stage, keys + b, cur_dst + b, not_large_rotation, res + b, 1);
+        if (rcs[r]) mb.err = nik_last_error(mb.ctx);
+    });
+    for (size_t r = 0; r < g->m.size(); ++r)
+        if (rcs[r]) return gfail(g, rcs[r], std::string("member ") + std::to_string(r) + ": " + g->m[r].err);
+    return NIK_OK;
+}
+
+// FindLoopClosure's candidate loop over a sharded key-frame store: the query frame (host u8 image) is uploaded to every
+// member (slot query_slot), each member registers it against its resident candidates (nik_match), the members' best
+// candidates are all-gathered and the reference's rule picks the winner.  cands[r][0..n_cands[r]) are slots of member r;
+// global candidate index = position in the concatenation over members.  best_member / best_local: where the winner lives.
+int nik_group_match(nik_group* g, const uint8_t* h_query, nik_frame query_slot, const int* n_cands, const nik_frame* const* cands,
+                    int* best_member, int* best_local, nik_pose_result* best) {
+    if (!g || !h_query || !n_cands || !cands || !best_member || !best_local) return NIK_ERR_INVALID_ARG;
+    if (g->m.size() != (size_t)g->world) return gfail(g, NIK_ERR_INVALID_ARG, "nik_group_match needs a local group");
+    int dims[6];
+    nik_get_dims(g->m[0].ctx, dims);
+    std::vector<int> gidx(g->m.size(), -1), first(g->m.size(), 0);
+    std::vector<nik_pose_result> lbest(g->m.size());
+    int off = 0;
+    for (size_t r = 0; r < g->m.size(); ++r) { first[r] = off; off += n_cands[r]; }
+    std::vector<int> rcs(g->m.size(), NIK_OK);
+    for_each_member(g->m.size(), [&](size_t r) {
+        Member& mb = g->m[r];
+        if (hipSetDevice(mb.device) != hipSuccess) { mb.err = "hipSetDevice failed"; rcs[r] = NIK_ERR_HIP; return; }
+        int rc = nik_intermedium_u8(mb.ctx, h_query, dims[1], query_slot);
+        int bi = -1;
+        if (!rc && n_cands[r] > 0) rc = nik_match(mb.ctx, query_slot, n_cands[r], cands[r], &bi, nullptr, &lbest[r]);
+        if (rc) { mb.err = nik_last_error(mb.ctx); rcs[r] = rc; return; }
+        gidx[r] = bi >= 0 ? first[r] + bi : -1;
+    });
+    for (size_t r = 0; r < g->m.size(); ++r)
+        if (rcs[r]) return gfail(g, rcs[r], std::string("member ") + std::to_string(r) + ": " + g->m[r].err);
+    int win = -1;
+    int rc = nik_group_gather_best(g, gidx.data(), lbest.data(), &win, best);
+    if (rc) return rc;
+    *best_member = -1; *best_local = -1;
+    for (size_t r = 0; r < g->m.size(); ++r)
+        if (win >= first[r] && win < first[r] + n_cands[r]) { *best_member = (int)r; *best_local = win - first[r]; }
+    return NIK_OK;
+}
+
+}  // extern "C"

@@ -184,6 +184,11 @@ void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int pa
                      SurfaceResult* out, int* rot_index, int n_hyp, int PD);
 
 
+// residual statistics of a batch call from its raw surface results: stats[4] = [sum PSR_t, sum PSR_r, sum |t|^2, count]
+void launch_residual_stats(hipStream_t s, const SurfaceResult* rot, const SurfaceResult* trans, int n, int n_hyp,
+                           int H, int W, int PD, int PC, double* stats);
+void launch_stats_sum(hipStream_t s, const double* parts, int n_parts, double* total);
+
 // layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]
 void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols);
 

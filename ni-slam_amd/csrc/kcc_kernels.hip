@@ -1563,6 +1563,45 @@ void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int pa
     hipLaunchKernelGGL(k_finalize, dim3(n_items), dim3(64), 0, s, partials, partial_stride, n_partials, out, rot_index, n_hyp, PD);
 }
 
+// Residual statistics of one batch call, on the device (north star: "RCCL all-reduce only for the final pose-graph residual
+// sum"): stats = [sum PSR_t (chosen hypothesis), sum PSR_r, sum |t|^2 (px^2), count] from the raw surface results, with
+// GetInfo (correlation_flow.cc:238-243) and the hypothesis choice (:121-131) evaluated as finalize_pose does on the host.
+// One wave, fixed summation order: deterministic.
+__device__ __forceinline__ float psr_dev(const SurfaceResult& r, long n) {
+    const double m = (r.sum - (double)r.peak) / (double)(n - 1);
+    double var = (r.sumsq - 2.0 * m * r.sum + (double)n * m * m) / (double)n;
+    if (var < 0) var = 0;
+    return (float)(((double)r.peak - m) / ((double)(float)sqrt(var) + 1e-7));
+}
+__global__ __launch_bounds__(64) void k_residual_stats(const SurfaceResult* __restrict__ rot, const SurfaceResult* __restrict__ trans,
+                                                       int n, int n_hyp, int H, int W, int PD, int PC, double* __restrict__ stats) {
+    double s[4] = { 0, 0, 0, 0 };
+    for (int i = threadIdx.x; i < n; i += 64) {
+        int h = 0;
+        float pt = psr_dev(trans[i * n_hyp], (long)H * W);
+        if (n_hyp == 2) { const float p1 = psr_dev(trans[i * 2 + 1], (long)H * W); if (!(pt > p1)) { pt = p1; h = 1; } }
+        const int idx = trans[i * n_hyp + h].idx;
+        const double t0 = -((idx % H) - H / 2), t1 = -((idx / H) - W / 2);
+        s[0] += (double)pt; s[1] += (double)psr_dev(rot[i], (long)PD * PC); s[2] += t0 * t0 + t1 * t1; s[3] += 1.0;
+    }
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += __shfl_xor(s[k], off);
+    if (threadIdx.x == 0) { stats[0] = s[0]; stats[1] = s[1]; stats[2] = s[2]; stats[3] = s[3]; }
+}
+void launch_residual_stats(hipStream_t st, const SurfaceResult* rot, const SurfaceResult* trans, int n, int n_hyp,
+                           int H, int W, int PD, int PC, double* stats) {
+    hipLaunchKernelGGL(k_residual_stats, dim3(1), dim3(64), 0, st, rot, trans, n, n_hyp, H, W, PD, PC, stats);
+}
+// total[0..3] = sum over `n_parts` partial blocks of 4 doubles, in index order
+__global__ void k_stats_sum(const double* __restrict__ parts, int n_parts, double* __restrict__ total) {
+    const int k = threadIdx.x;
+    if (k < 4) { double a = 0; for (int p = 0; p < n_parts; ++p) a += parts[4 * p + k]; total[k] = a; }
+}
+void launch_stats_sum(hipStream_t st, const double* parts, int n_parts, double* total) {
+    hipLaunchKernelGGL(k_stats_sum, dim3(1), dim3(4), 0, st, parts, n_parts, total);
+}
+
 // RemoveZeroComponent (correlation_flow.cc:79-87) on the shifted plane S: p(r,c) lives at S[(c+W/2)%W][(r+H/2)%H].
 //   column c=0 (all r):  (p(r,1) + p(r,W-1))/2   -- reads the ORIGINAL columns 1 and W-1, so it runs first
 //   row r=0 (c != 0):    (p(1,c) + p(H-1,c))/2

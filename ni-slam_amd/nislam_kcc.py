@@ -29,7 +29,12 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
-           "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom"]
+           "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
+           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats",
+           "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
+           "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard",
+           "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
+           "nik_group_match"]
 
 
 class NikConfig(C.Structure):
@@ -185,6 +190,29 @@ def load():
         L.nik_tracker_push_u8.argtypes = [P, P, I, P]
         L.nik_tracker_keyframes.argtypes = [P, P, I, P]
         L.nik_profile_read.argtypes = [P, P, I, P]
+        L.nik_set_residual_stats.argtypes = [P, I]
+        L.nik_residual_stats.argtypes = [P, P]
+        L.nik_residual_stats_dev.argtypes = [P, P, P]
+        L.nik_device.argtypes = [P]
+        L.nik_group_last_error.restype = C.c_char_p
+        L.nik_group_last_error.argtypes = [P]
+        L.nik_group_unique_id.argtypes = [P]
+        L.nik_group_create_rank.argtypes = [P, I, I, P, P]
+        L.nik_group_create_local.argtypes = [C.POINTER(NikConfig), I, I, I, I, I, P, P]
+        L.nik_group_destroy.argtypes = [P]
+        L.nik_group_destroy.restype = None
+        L.nik_group_world.argtypes = [P]
+        L.nik_group_local_count.argtypes = [P]
+        L.nik_group_ctx.argtypes = [P, I]
+        L.nik_group_ctx.restype = P
+        L.nik_group_rank.argtypes = [P, I]
+        L.nik_group_shard.argtypes = [I, I, I, P, P]
+        L.nik_group_shard.restype = None
+        L.nik_group_allreduce_residual.argtypes = [P, P]
+        L.nik_group_residual_result.argtypes = [P, P]
+        L.nik_group_gather_best.argtypes = [P, P, P, P, P]
+        L.nik_group_track_batch.argtypes = [P, I, P, P, P, I, P]
+        L.nik_group_match.argtypes = [P, P, I, P, P, P, P, P]
         L.nik_host_polar_plan.argtypes = [I, I, I, I, P, P, P, P, P]
         L.nik_host_free.argtypes = [P]
         L.nik_host_free.restype = None
@@ -265,10 +293,32 @@ class CorrelationFlow:
         self.PD, self.PC = cfg.rotation_divisor, cfg.rotation_channel
         self.max_batch, self.max_frames = max_batch, max_frames
 
+    @classmethod
+    def borrow(cls, ctx, cfg, image_height, image_width, max_batch, max_frames):
+        """a view of a context owned by someone else (a local nik_group): close() leaves it alone"""
+        self = cls.__new__(cls)
+        self._L = load()
+        self._ctx = C.c_void_p(ctx)
+        self._borrowed = True
+        self.cfg, self.H, self.W = cfg, int(image_height), int(image_width)
+        self.PD, self.PC = cfg.rotation_divisor, cfg.rotation_channel
+        self.max_batch, self.max_frames = max_batch, max_frames
+        return self
+
     def close(self):
         if getattr(self, "_ctx", None):
-            self._L.nik_destroy(self._ctx)
+            if not getattr(self, "_borrowed", False):
+                self._L.nik_destroy(self._ctx)
             self._ctx = None
+
+    # ---- residual statistics of the latest batch, reduced on the device ---------------------
+    def set_residual_stats(self, on=True):
+        self._chk(self._L.nik_set_residual_stats(self._ctx, int(bool(on))))
+
+    def residual_stats(self):
+        out = np.zeros(4, np.float64)
+        self._chk(self._L.nik_residual_stats(self._ctx, _p(out)))
+        return out
 
     __del__ = close
 
@@ -446,6 +496,104 @@ class CorrelationFlow:
         out = np.empty((self.PC, self.PD) if which == 0 else (self.W, self.H), np.float32)
         self._chk(self._L.nik_dbg_response(self._ctx, int(which), int(key), int(cur), int(degree2), _p(out)))
         return out
+
+
+class Group:
+    """nik_group: the contexts of several GPUs plus the RCCL communicator for the residual all-reduce and the
+    best-candidate all-gather.  Group.local(...) drives every GPU from this process; Group.rank(cf, rank, world, id) is the
+    one-process-per-GPU form (id = Group.unique_id() of rank 0, broadcast by the launcher)."""
+
+    def __init__(self, handle, flows):
+        self._L = load()
+        self._g = handle
+        self.flows = flows
+
+    @staticmethod
+    def unique_id():
+        buf = np.zeros(128, np.uint8)
+        L = load()
+        rc = L.nik_group_unique_id(_p(buf))
+        if rc:
+            raise NikError(rc, L.nik_group_last_error(None).decode())
+        return buf
+
+    @classmethod
+    def local(cls, cfg, image_height, image_width, max_batch=8, max_frames=64, devices=(0,)):
+        L = load()
+        g = C.c_void_p()
+        dv = _i32(devices)
+        rc = L.nik_group_create_local(C.byref(cfg), int(image_height), int(image_width), int(max_batch), int(max_frames), len(dv), _p(dv), C.byref(g))
+        if rc:
+            raise NikError(rc, L.nik_group_last_error(None).decode())
+        flows = [CorrelationFlow.borrow(L.nik_group_ctx(g, i), cfg, image_height, image_width, max_batch, max_frames) for i in range(len(dv))]
+        return cls(g, flows)
+
+    @classmethod
+    def rank(cls, flow, rank, world, uid=None):
+        L = load()
+        g = C.c_void_p()
+        rc = L.nik_group_create_rank(flow._ctx, int(rank), int(world), _p(uid) if uid is not None else None, C.byref(g))
+        if rc:
+            raise NikError(rc, L.nik_group_last_error(None).decode())
+        return cls(g, [flow])
+
+    def _chk(self, rc):
+        if rc:
+            raise NikError(rc, self._L.nik_group_last_error(self._g).decode())
+
+    @property
+    def world(self):
+        return self._L.nik_group_world(self._g)
+
+    @staticmethod
+    def shard(n, world, rank):
+        b, e = C.c_int(), C.c_int()
+        load().nik_group_shard(int(n), int(world), int(rank), C.byref(b), C.byref(e))
+        return b.value, e.value
+
+    def allreduce_residual(self, wait=True):
+        out = np.zeros(4, np.float64)
+        self._chk(self._L.nik_group_allreduce_residual(self._g, _p(out) if wait else None))
+        return out if wait else None
+
+    def residual_result(self):
+        out = np.zeros(4, np.float64)
+        self._chk(self._L.nik_group_residual_result(self._g, _p(out)))
+        return out
+
+    def gather_best(self, global_index, local_best):
+        gi = _i32(global_index)
+        arr = (NikPoseResult * len(gi))(*local_best)
+        best = C.c_int(-1)
+        res = NikPoseResult()
+        self._chk(self._L.nik_group_gather_best(self._g, _p(gi), C.addressof(arr), C.byref(best), C.addressof(res)))
+        return best.value, (res.as_dict() if best.value >= 0 else None)
+
+    def track_batch(self, gray, keys, cur_dst, not_large_rotation=True):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        n = gray.shape[0]
+        k, d = _i32(keys), _i32(cur_dst)
+        res = (NikPoseResult * n)()
+        self._chk(self._L.nik_group_track_batch(self._g, n, _p(gray), _p(k), _p(d), int(bool(not_large_rotation)), C.addressof(res)))
+        return [r.as_dict() for r in res]
+
+    def match(self, query, query_slot, cands_per_member):
+        query = np.ascontiguousarray(query, np.uint8)
+        arrs = [_i32(c) for c in cands_per_member]
+        nc = _i32([len(a) for a in arrs])
+        ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+        bm, bl = C.c_int(-1), C.c_int(-1)
+        res = NikPoseResult()
+        self._chk(self._L.nik_group_match(self._g, _p(query), int(query_slot), _p(nc), ptrs, C.byref(bm), C.byref(bl), C.addressof(res)))
+        return bm.value, bl.value, (res.as_dict() if bm.value >= 0 else None)
+
+    def close(self):
+        if getattr(self, "_g", None):
+            for f in self.flows:
+                if getattr(f, "_borrowed", False):
+                    f._ctx = None
+            self._L.nik_group_destroy(self._g)
+            self._g = None
 
 
 def tracker_config(fx=600.0, fy=600.0, cx=320.0, cy=240.0, height=0.1, max_distance=0.4, max_angle=0.052359877,

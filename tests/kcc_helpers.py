@@ -83,3 +83,16 @@ def _compare(gpu, ora_pose, ora_info, psr_rtol):
         if abs(gpu["info"][k] - ora_info[k]) > psr_rtol * abs(ora_info[k]):
             msgs.append("info[%d] gpu=%r oracle=%r" % (k, gpu["info"][k], ora_info[k]))
     return (not msgs), True, "; ".join(msgs)
+
+
+def imposed_rerun(ocfg, H, W, key_img, cur_img, not_large_rotation):
+    """rerun callable for check_pose_parity: the oracle's ComputePose for one u8 pair with the rotation arg-max imposed"""
+    def rerun(row, col):
+        from oracle import kcc_oracle as ko
+        o = ko.Oracle(ocfg, H, W)
+        o.force_rotation(row, col)
+        kf, kp = o.intermedium(o.normalize_u8(key_img))
+        x = o.normalize_u8(cur_img)
+        _, xp = o.intermedium(x)
+        return o.compute_pose(kf, x, kp, xp, not_large_rotation)
+    return rerun

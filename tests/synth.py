@@ -46,3 +46,25 @@ def make_batch(n, H, W, seed0=0, max_shift=None, max_theta=10.0, half_degree=Fal
         keys[i], curs[i] = make_pair(seed0 + i, H, W, dy, dx, th)
         motions.append((dy, dx, th))
     return keys, curs, motions
+
+
+def make_unique_batch(n, H, W, seed0=0, max_theta=10.0, ncanvas=32, max_shift=48, base_shift=60):
+    """n pairs with pairwise DIFFERENT images: pair i uses canvas i % ncanvas and its own key window on it; the current
+    frame is the key window moved by (dy, dx) and rotated by theta about the key window's centre."""
+    rng = np.random.default_rng(seed0)
+    cvs = [canvas(seed0 + c, H, W) for c in range(min(ncanvas, n))]
+    keys = np.empty((n, H, W), np.uint8)
+    curs = np.empty((n, H, W), np.uint8)
+    motions = []
+    for i in range(n):
+        cv = cvs[i % len(cvs)]
+        by, bx = (int(v) for v in rng.integers(-base_shift, base_shift + 1, 2))
+        dy, dx = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
+        th = float(rng.uniform(-max_theta, max_theta)) if max_theta > 0 else 0.0
+        keys[i] = window(cv, H, W, by, bx)
+        if th != 0.0:
+            curs[i] = window(np.roll(cv, (-by, -bx), axis=(0, 1)), H, W, dy, dx, th)    # key centre moved to the canvas centre first
+        else:
+            curs[i] = window(cv, H, W, by + dy, bx + dx)
+        motions.append((dy, dx, th))
+    return keys, curs, motions

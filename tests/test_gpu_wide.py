@@ -38,24 +38,8 @@ def _mk(kernel=0, max_batch=8, max_frames=32):
     return N.CorrelationFlow(cfg, H, W, max_batch=max_batch, max_frames=max_frames), ko.Oracle(ocfg, H, W), ocfg
 
 
-def unique_batch(n, seed0, max_theta, ncanvas=32, max_shift=48):
-    """n pairs with pairwise different images: pair i uses canvas i % ncanvas and its own key window"""
-    rng = np.random.default_rng(seed0)
-    cvs = [synth.canvas(seed0 + c, H, W) for c in range(min(ncanvas, n))]
-    keys = np.empty((n, H, W), np.uint8); curs = np.empty((n, H, W), np.uint8); motions = []
-    for i in range(n):
-        cv = cvs[i % len(cvs)]
-        by, bx = (int(v) for v in rng.integers(-60, 61, 2))                 # key window: its own place on the canvas
-        dy, dx = (int(v) for v in rng.integers(-max_shift, max_shift + 1, 2))
-        th = float(rng.uniform(-max_theta, max_theta))
-        keys[i] = synth.window(cv, H, W, by, bx)
-        if th != 0.0:
-            # rotate about the KEY window's centre: roll the canvas so that centre sits at the canvas centre first
-            cv2 = np.roll(cv, (-by, -bx), axis=(0, 1))
-            curs[i] = synth.window(cv2, H, W, dy, dx, th)
-        else:
-            curs[i] = synth.window(cv, H, W, by + dy, bx + dx)
-        motions.append((dy, dx, th))
+def unique_batch(n, seed0, max_theta):
+    keys, curs, motions = synth.make_unique_batch(n, H, W, seed0=seed0, max_theta=max_theta)
     assert len({k.tobytes() for k in keys}) == n and len({c.tobytes() for c in curs}) == n
     return keys, curs, motions
 
@@ -148,13 +132,7 @@ def test_unique_pairs_parity(small_rot, max_theta):
         for i in range(B):
             p = b + i
 
-            def rerun(row, col, p=p):
-                o = ko.Oracle(ocfg, H, W)
-                o.force_rotation(row, col)
-                kf, kp = o.intermedium(o.normalize_u8(keys[p]))
-                x = o.normalize_u8(curs[p])
-                _, xp = o.intermedium(x)
-                return o.compute_pose(kf, x, kp, xp, small_rot)
+            rerun = kcc_helpers.imposed_rerun(ocfg, H, W, keys[p], curs[p], small_rot)
             ok, exact, msg = check_pose_parity(res[i], poses[p], infos[p], dbgs[p], PD, rerun=rerun)
             assert ok, "pair %d motion %s: %s" % (p, motions[p], msg)
             if exact:

@@ -1,0 +1,129 @@
+"""nik_group (multi-GPU C ABI): what a 1-GPU box can check.
+
+* nik_group_shard partitions like kcc_dist.shard_range (CPU).
+* a local group of one GPU: sharded tracking / loop closure through the group equal the direct context calls bit for bit,
+  and the device-reduced residual statistics equal the host sum over the per-pair results.
+* the same through RCCL itself (NIK_GROUP_FORCE_RCCL=1: ncclCommInitAll / ncclCommInitRank with one rank, all-reduce and
+  all-gather on the device) -- exercises the dlopen'ed RCCL call path; communicators of more than one GPU need the 8-GPU node.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import synth
+from kcc_helpers import PKG, SMALL, load_module, nik
+
+kd = load_module("kcc_dist", os.path.join(PKG, "kcc_dist.py"))
+
+
+def test_group_shard_partitions_like_the_python_glue():
+    N = nik()
+    for n in (0, 1, 7, 32, 255, 256, 4096):
+        for world in (1, 2, 3, 8):
+            cover = []
+            for r in range(world):
+                b, e = N.Group.shard(n, world, r)
+                assert (b, e) == kd.shard_range(n, world, r)
+                cover += list(range(b, e))
+            assert cover == list(range(n))
+
+
+def _host_stats(res):
+    return np.array([sum(r["info"][0] for r in res), sum(r["info"][2] for r in res),
+                     sum(r["pose"][0] ** 2 + r["pose"][1] ** 2 for r in res), float(len(res))])
+
+
+def _group_checks():
+    N = nik()
+    g = SMALL
+    cfg = N.default_config(rotation_divisor=g["PD"], rotation_channel=g["PC"])
+    n = 24
+    keys, curs, _ = synth.make_batch(n, g["H"], g["W"], seed0=70)
+    # direct context
+    cf = N.CorrelationFlow(cfg, g["H"], g["W"], max_batch=n, max_frames=2 * n + 2)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+    import torch
+    dc = torch.from_numpy(curs).cuda()
+    torch.cuda.synchronize()
+    cf.set_residual_stats(True)
+    want = [r.as_dict() for r in cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)]
+    st = cf.residual_stats()
+    assert np.allclose(st, _host_stats(want), rtol=1e-12, atol=0) and st[3] == n
+    want_lr = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), False)
+    assert np.allclose(cf.residual_stats(), _host_stats(want_lr), rtol=1e-12, atol=0)
+    cf.intermedium_u8(curs[3], 2 * n)
+    bi, _, bres = cf.match(2 * n, list(range(n)))
+    # local group of one GPU
+    grp = N.Group.local(cfg, g["H"], g["W"], max_batch=n, max_frames=2 * n + 2, devices=[0])
+    assert grp.world == 1
+    f0 = grp.flows[0]
+    for i in range(n):
+        f0.intermedium_u8(keys[i], i)
+    got = grp.track_batch(curs, list(range(n)), list(range(n, 2 * n)), True)
+    assert got == want
+    assert np.allclose(grp.allreduce_residual(), _host_stats(want), rtol=1e-12, atol=0)
+    grp.allreduce_residual(wait=False)
+    assert np.allclose(grp.residual_result(), _host_stats(want), rtol=1e-12, atol=0)
+    bm, bl, gres = grp.match(curs[3], 2 * n, [list(range(n))])
+    assert (bm, bl) == (0, bi) and gres == bres
+    assert grp.gather_best([-1], [N.NikPoseResult()])[0] == -1
+    grp.close()
+    # one-process-per-GPU form, world of one
+    grp2 = N.Group.rank(cf, 0, 1)
+    cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)
+    assert np.allclose(grp2.allreduce_residual(), _host_stats(want), rtol=1e-12, atol=0)
+    grp2.close()
+    cf.close()
+
+
+@pytest.mark.gpu
+def test_local_group_of_one_gpu_equals_direct_calls():
+    _group_checks()
+
+
+@pytest.mark.gpu
+def test_group_through_rccl_single_rank():
+    """the same checks with the collectives going through RCCL (own process: the switch is read at group creation)"""
+    env = dict(os.environ, NIK_GROUP_FORCE_RCCL="1")
+    code = "import sys; sys.path[:0] = [%r, %r]; import test_group; test_group._group_checks(); print('RCCL-OK')" % (
+        os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+
+
+def _run_bench(world, gb, dump, tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIK_BENCH_GLOBAL_BATCH=str(gb), NIK_BENCH_DUMP=str(dump), NIK_BENCH_DEVICE="0", NIK_BENCH_BACKEND="gloo")
+    common = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-profile", "--no-cached"]
+    if world == 1:
+        cmd = [sys.executable] + common
+    else:
+        port = 29600 + (os.getpid() % 1000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(port)] + common
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    import json
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    return line, [json.load(open("%s.%d" % (dump, r))) for r in range(world)]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_two_ranks_on_one_device_equal_one_rank(tmp_path):
+    """the HIP path run as two ranks (each its contiguous shard of ONE global batch; both on device 0, gloo for the
+    rendezvous) gives bit for bit the per-pair results of the unsharded run, and the all-reduced statistics agree"""
+    gb = 48
+    line1, d1 = _run_bench(1, gb, tmp_path / "w1", tmp_path)
+    line2, d2 = _run_bench(2, gb, tmp_path / "w2", tmp_path)
+    assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
+    whole = d1[0]["results"]
+    parts = d2[0]["results"] + d2[1]["results"]
+    assert len(whole) == gb == len(parts)
+    assert parts == whole
+    s1 = np.array(d1[0]["stats"]); s2 = np.array(d2[0]["stats"])
+    assert s1[3] == gb == s2[3] and np.allclose(s1, s2, rtol=1e-12, atol=0) and np.array_equal(np.array(d2[1]["stats"]), s2)
