@@ -321,6 +321,21 @@ typedef struct {
 int nik_profile_enable(nik_ctx* ctx, int enable);
 int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);
 
+/* Small batches are bound by the latency of their ~16 dependent kernel launches: with max_pairs > 0, nik_pose / nik_pose_batch
+ * calls of at most that many stored u8 frames (one stream, Kzz cache off) are captured once into a hipGraph per batch
+ * size and replayed.  Results are identical.  0 = off (default; $NIK_GRAPH sets the default). */
+int nik_set_graphs(nik_ctx* ctx, int max_pairs);
+
+/* ---- coarse-to-fine chaining on the device (used by nik_pyramid; BASELINE config 3, an extension) ------------------
+ * nik_pose_batch_window with the window centres predicted, on the device, from the peaks `upper` (a coarser level's
+ * context on the same device) found in its latest pose call over the same n pairs.  No host round trip between levels. */
+int nik_pose_batch_chained(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs, nik_ctx* upper, int radius,
+                           nik_pose_result* res, int sync);
+/* every stream of ctx waits for the work `other` (same device) has enqueued so far */
+int nik_wait_for(nik_ctx* ctx, nik_ctx* other);
+/* nik_downsample_u8_dev, asynchronous on nik_stream(ctx) */
+int nik_downsample_u8_async(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out);
+
 /* ---- residual statistics of a batch, reduced on the device --------------------------------------
  * stats = [sum PSR_t (chosen hypothesis), sum PSR_r, sum |t|^2 (px^2), count] over the pairs of the latest
  * nik_pose_batch / nik_track_batch_dev / nik_match call: the per-batch "residual sum" that a multi-GPU run all-reduces

@@ -70,6 +70,9 @@ struct Lane {
     int* d_idx = nullptr;
     Call ring[2]; int next = 0;
     Call* cur = nullptr;                // call being enqueued
+    // hipGraph replay of the pose chain for small batches (nik_set_graphs): one executable per (ring entry, n, mode)
+    struct PoseGraph { int slot, n, flags; hipGraphExec_t exec; int uses; };
+    std::vector<PoseGraph> graphs;
 };
 
 }  // namespace
@@ -108,6 +111,10 @@ struct nik_ctx {
     // They are summed (and all-reduced, nik_group) on their own stream so that no lane waits for another.
     bool want_stats = false; double* d_stats = nullptr; double* h_stats = nullptr; int stats_lanes = 0;
     hipStream_t stats_stream = nullptr; hipEvent_t stats_done = nullptr; bool stats_pending = false;
+    int graph_max = 0;                   // batches of <= graph_max pairs replay a captured hipGraph (0: off); $NIK_GRAPH
+    hipEvent_t fence_ev = nullptr;       // nik_wait_for
+    hipEvent_t chain_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // a finer pyramid level has read lane li's surface results
+    bool chain_pending[4] = { false, false, false, false };
     PolarPlan polar{};                   // gather tables of the polar forward kernel (device pointers; kcc_tables.cpp)
     int* rot_one = nullptr;              // one-angle de-rotation table (nik_dbg_rotate)
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
@@ -316,6 +323,8 @@ int begin_call(nik_ctx* c, Lane& L) {
     int rc = retire(c, call);
     if (rc) return rc;
     L.cur = &call; L.next ^= 1; L.call_seq += 1;
+    const int li = (int)(&L - c->lanes.data());
+    if (c->chain_pending[li]) { HIP_TRY(c, hipStreamWaitEvent(L.stream, c->chain_ev[li], 0)); c->chain_pending[li] = false; }
     return NIK_OK;
 }
 int end_call(nik_ctx* c, Lane& L) {
@@ -598,6 +607,7 @@ void lane_free(Lane& L) {
         if (call.h_trans) (void)hipHostFree(call.h_trans);
         if (call.done) (void)hipEventDestroy(call.done);
     }
+    for (auto& g : L.graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (L.write_ev) (void)hipEventDestroy(L.write_ev);
     if (L.tail_ev) (void)hipEventDestroy(L.tail_ev);
     if (L.stream) (void)hipStreamDestroy(L.stream);
@@ -656,6 +666,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
     if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
     if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
+    if (const char* e = getenv("NIK_GRAPH")) c->graph_max = std::max(0, atoi(e));
     c->slot_kind.assign(max_frames, 0);
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 2;
@@ -684,6 +695,8 @@ void nik_destroy(nik_ctx* c) {
     if (c->stats_done) (void)hipEventDestroy(c->stats_done);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(const_cast<uint32_t*>(c->polar.chunks)); (void)hipFree(const_cast<int*>(c->polar.seg_first));
     (void)hipFree(const_cast<uint4*>(c->polar.pts)); (void)hipFree(c->rot_tab); (void)hipFree(c->rot_one);
+    for (hipEvent_t e : c->chain_ev) if (e) (void)hipEventDestroy(e);
+    if (c->fence_ev) (void)hipEventDestroy(c->fence_ev);
     for (auto& r : c->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto e : c->prof_pool) (void)hipEventDestroy(e);
     delete c;
@@ -744,6 +757,16 @@ int nik_residual_stats(nik_ctx* c, double out[4]) {
     HIP_TRY(c, hipMemcpyAsync(c->h_stats, d, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stats_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stats_stream));
     memcpy(out, c->h_stats, sizeof(double) * 4);
+    return NIK_OK;
+}
+
+// batches of <= max_pairs stored frames (nik_pose_batch / nik_pose / nik_match chunks on one stream, Kzz cache off) replay a
+// captured hipGraph instead of ~16 separate launches; 0 switches it off
+int nik_set_graphs(nik_ctx* c, int max_pairs) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    int rc = drain_all(c);
+    if (rc) return rc;
+    c->graph_max = std::max(0, max_pairs);
     return NIK_OK;
 }
 
@@ -952,11 +975,15 @@ static int ensure_kzz_run(nik_ctx* c, Lane& L, const std::vector<nik_frame>& tod
 }
 
 // shared body of nik_pose_batch / nik_track_batch_dev
+// upper != null: the arg-max windows are centred where `upper`'s latest pose call (same n, same stream split) found its peaks,
+// predicted on the device (coarse-to-fine chaining).
 static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* keys, const nik_frame* curs,
-                     int not_large_rotation, nik_pose_result* res, const int32_t* win_centers = nullptr, int win_radius = -1) {
+                     int not_large_rotation, nik_pose_result* res, const int32_t* win_centers = nullptr, int win_radius = -1,
+                     nik_ctx* upper = nullptr) {
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
+    if (upper && lanes_for(upper, n) != nl) return fail(c, NIK_ERR_INVALID_ARG, "chained levels must split the batch over the same number of streams");
     c->stats_lanes = 0;
     for (int li = 0; li < nl; ++li) {
         int b, e; chunk_of(n, nl, li, b, e);
@@ -969,37 +996,84 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             if (d_gray) { if ((rc = depend_for_write(c, L, li, curs[i]))) return rc; }
             else { if ((rc = depend_on_slot(c, L, li, curs[i]))) return rc; note_read(c, L, li, curs[i]); }
         }
-        if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
-        if (win_centers) {
-            for (int i = 0; i < m; ++i) {
-                const int32_t* w = win_centers + 4 * (size_t)(b + i);
-                hidx(L, IX_WRR)[i] = w[0]; hidx(L, IX_WRC)[i] = w[1]; hidx(L, IX_WTR)[i] = w[2]; hidx(L, IX_WTC)[i] = w[3];
+        // Small stored-frame batches are latency-bound by their ~16 dependent launches: replay them as one hipGraph (index
+        // upload, kernels and result copies captured once per (ring entry, n, mode); all pointers are call-invariant).
+        bool graphable = c->graph_max > 0 && !d_gray && !upper && !win_centers && nl == 1 && m <= c->graph_max && !c->prof_on;
+        if (graphable) for (int i = b; i < e; ++i) if (!(c->slot_kind[curs[i]] & 1)) graphable = false;
+        Lane::PoseGraph* pg = nullptr;
+        const int gslot = (int)(L.cur - L.ring), gflags = (not_large_rotation ? 1 : 0) | (c->want_stats ? 2 : 0) | (c->kzz_cache ? 4 : 0);
+        if (graphable) {
+            for (auto& g : L.graphs) if (g.slot == gslot && g.n == m && g.flags == gflags) pg = &g;
+            // the first batch of a shape runs the ordinary way (it may initialise per-kernel launch attributes, which a
+            // capture must not contain); the second one is captured
+            if (!pg) { L.graphs.push_back({ gslot, m, gflags, nullptr, 0 }); graphable = false; }
+        }
+        if (graphable) {
+            const int slot = gslot, flags = gflags;
+            // fill the pinned index arrays (the captured copy node reads them at replay time)
+            const int n_hyp = not_large_rotation ? 1 : 2;
+            for (int i = 0; i < m; ++i) { hidx(L, IX_KEY)[i] = keys[b + i]; hidx(L, IX_CUR)[i] = curs[b + i]; }
+            for (int t = 0; t < m * n_hyp; ++t) { hidx(L, IX_TIMG)[t] = curs[b + t / n_hyp]; hidx(L, IX_TKEY)[t] = keys[b + t / n_hyp]; }
+            if (!pg->exec) {
+                hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+                HIP_TRY(c, hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+                rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, false);
+                if (!rc) rc = enqueue_pose(c, L, m, not_large_rotation, true, false, -1);
+                if (!rc && c->want_stats)
+                    launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, n_hyp, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
+                const hipError_t ce = hipStreamEndCapture(L.stream, &graph);
+                if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+                HIP_TRY(c, ce);
+                HIP_TRY(c, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(graph);
+                pg->exec = exec; (void)slot; (void)flags;
             }
-            HIP_TRY(c, hipMemcpyAsync(L.d_idx + (size_t)L.cap_items * IX_WRR, L.cur->h_idx + (size_t)L.cap_items * IX_WRR,
-                                      sizeof(int) * (size_t)L.cap_items * 4, hipMemcpyHostToDevice, L.stream));
-        }
-        bool fuse = false, img_u8 = true;
-        if (d_gray) {
-            // the polar spectrum's last pass is fused into the pose's first kernel (not for the gaussian kernel,
-            // which needs sum|X|^2 of the finished spectrum before that kernel runs)
-            fuse = (c->cfg.kernel != 1) && c->fuse_polar;
-            enqueue_intermedium(c, L, m, d_gray + (size_t)b * c->img.real_elems, fuse);
-            // (fused: the frames' polar spectra are completed by the pose's first kernel -- the write event other
-            // lanes wait on must come after it)
-            if (!fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
+            if (c->want_stats) { if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0)); c->stats_lanes = std::max(c->stats_lanes, li + 1); }
+            HIP_TRY(c, hipGraphLaunch(pg->exec, L.stream));
+            pg->uses += 1;
         } else {
-            // stored frames: de-rotate from the u8 frame store when every current frame has a u8 image; a batch that
-            // mixes in f32 frames (nik_intermedium_f32 / nik_frame_import) runs on f32 planes, materialised on demand
-            for (int i = b; i < e; ++i) if (!(c->slot_kind[curs[i]] & 1)) img_u8 = false;
-            if (!img_u8 && (rc = ensure_f32_images(c, L, li, m, curs + b))) return rc;
+            if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
+            if (upper) {
+                Lane& U = upper->lanes[li];
+                HIP_TRY(c, hipStreamWaitEvent(L.stream, U.tail_ev, 0));       // the level above has enqueued its share already
+                launch_predict_windows(L.stream, U.rot_res, U.trans_res, m, upper->PD, upper->PC, upper->H, upper->W, c->PD, c->PC, c->H, c->W,
+                                       didx(L, IX_WRR), didx(L, IX_WRC), didx(L, IX_WTR), didx(L, IX_WTC));
+                // (upper must not overwrite those results before this lane has read them)
+                if (!upper->chain_ev[li]) HIP_TRY(c, hipEventCreateWithFlags(&upper->chain_ev[li], hipEventDisableTiming));
+                HIP_TRY(c, hipEventRecord(upper->chain_ev[li], L.stream));
+                upper->chain_pending[li] = true;
+            }
+            if (win_centers) {
+                for (int i = 0; i < m; ++i) {
+                    const int32_t* w = win_centers + 4 * (size_t)(b + i);
+                    hidx(L, IX_WRR)[i] = w[0]; hidx(L, IX_WRC)[i] = w[1]; hidx(L, IX_WTR)[i] = w[2]; hidx(L, IX_WTC)[i] = w[3];
+                }
+                HIP_TRY(c, hipMemcpyAsync(L.d_idx + (size_t)L.cap_items * IX_WRR, L.cur->h_idx + (size_t)L.cap_items * IX_WRR,
+                                          sizeof(int) * (size_t)L.cap_items * 4, hipMemcpyHostToDevice, L.stream));
+            }
+            bool fuse = false, img_u8 = true;
+            if (d_gray) {
+                // the polar spectrum's last pass is fused into the pose's first kernel (not for the gaussian kernel,
+                // which needs sum|X|^2 of the finished spectrum before that kernel runs)
+                fuse = (c->cfg.kernel != 1) && c->fuse_polar;
+                enqueue_intermedium(c, L, m, d_gray + (size_t)b * c->img.real_elems, fuse);
+                // (fused: the frames' polar spectra are completed by the pose's first kernel -- the write event other
+                // lanes wait on must come after it)
+                if (!fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
+            } else {
+                // stored frames: de-rotate from the u8 frame store when every current frame has a u8 image; a batch that
+                // mixes in f32 frames (nik_intermedium_f32 / nik_frame_import) runs on f32 planes, materialised on demand
+                for (int i = b; i < e; ++i) if (!(c->slot_kind[curs[i]] & 1)) img_u8 = false;
+                if (!img_u8 && (rc = ensure_f32_images(c, L, li, m, curs + b))) return rc;
+            }
+            if ((rc = enqueue_pose(c, L, m, not_large_rotation, img_u8, fuse, (win_centers || upper) ? win_radius : -1))) return rc;
+            if (c->want_stats) {                                  // this lane's share of the batch's residual statistics
+                if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0));   // (the previous batch's partials are consumed)
+                launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, not_large_rotation ? 1 : 2, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
+                c->stats_lanes = std::max(c->stats_lanes, li + 1);
+            }
+            if (fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
         }
-        if ((rc = enqueue_pose(c, L, m, not_large_rotation, img_u8, fuse, win_centers ? win_radius : -1))) return rc;
-        if (c->want_stats) {                                  // this lane's share of the batch's residual statistics
-            if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0));   // (the previous batch's partials are consumed)
-            launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, not_large_rotation ? 1 : 2, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
-            c->stats_lanes = std::max(c->stats_lanes, li + 1);
-        }
-        if (fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = true; L.cur->n = m; L.cur->n_hyp = not_large_rotation ? 1 : 2; L.cur->res = res ? res + b : nullptr;
         if ((rc = end_call(c, L))) return rc;
@@ -1034,6 +1108,42 @@ int nik_pose_batch_window(nik_ctx* c, int n, const nik_frame* keys, const nik_fr
     }
     if ((rc = pose_call(c, n, nullptr, keys, curs, 1, res, centers, radius))) return rc;
     return drain_all(c);
+}
+
+// Coarse-to-fine chaining: nik_pose_batch_window whose window centres come, on the device, from `upper`'s latest pose call
+// over the same n pairs.  Asynchronous unless sync.
+int nik_pose_batch_chained(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, nik_ctx* upper, int radius,
+                           nik_pose_result* res, int sync) {
+    if (!c || !upper || !keys || !curs || n < 0 || radius < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (upper->device != c->device) return fail(c, NIK_ERR_INVALID_ARG, "chained levels must live on one device");
+    int rc;
+    if ((rc = check_kernel(c))) return rc;
+    if (n == 0) return NIK_OK;
+    if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
+    for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
+    if ((rc = pose_call(c, n, nullptr, keys, curs, 1, res, nullptr, radius, upper))) return rc;
+    return sync ? drain_all(c) : NIK_OK;
+}
+
+// every stream of c waits for the work `other` (same device) has enqueued so far
+int nik_wait_for(nik_ctx* c, nik_ctx* other) {
+    if (!c || !other) return NIK_ERR_INVALID_ARG;
+    if (other->device != c->device) return fail(c, NIK_ERR_INVALID_ARG, "contexts on different devices");
+    if (!other->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&other->fence_ev, hipEventDisableTiming));
+    for (Lane& O : other->lanes) {
+        HIP_TRY(c, hipEventRecord(other->fence_ev, O.stream));
+        for (Lane& L : c->lanes) HIP_TRY(c, hipStreamWaitEvent(L.stream, other->fence_ev, 0));
+    }
+    return NIK_OK;
+}
+
+// nik_downsample_u8_dev without the drain: enqueued on nik_stream(ctx)
+int nik_downsample_u8_async(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_out) {
+    if (!c || !d_in || !d_out || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (n == 0) return NIK_OK;
+    launch_downsample_u8(c->lanes[0].stream, n, d_in, d_out, c->H, c->W);
+    HIP_TRY(c, hipGetLastError());
+    return NIK_OK;
 }
 
 int nik_downsample_u8_dev(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_out) {

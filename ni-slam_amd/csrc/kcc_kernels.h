@@ -189,6 +189,10 @@ void launch_residual_stats(hipStream_t s, const SurfaceResult* rot, const Surfac
                            int H, int W, int PD, int PC, double* stats);
 void launch_stats_sum(hipStream_t s, const double* parts, int n_parts, double* total);
 
+// window centres of a level from the surface results of the level above (coarse-to-fine chaining on the device)
+void launch_predict_windows(hipStream_t s, const SurfaceResult* rot, const SurfaceResult* trans, int n, int PDu, int PCu, int Hu, int Wu,
+                            int PD, int PC, int H, int W, int* wrr, int* wrc, int* wtr, int* wtc);
+
 // layout conversion for export / import: reference [cols][hr] <-> internal [hr][cols]
 void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols);
 

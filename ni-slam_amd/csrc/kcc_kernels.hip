@@ -1602,6 +1602,29 @@ void launch_stats_sum(hipStream_t st, const double* parts, int n_parts, double* 
     hipLaunchKernelGGL(k_stats_sum, dim3(1), dim3(4), 0, st, parts, n_parts, total);
 }
 
+// Coarse-to-fine chaining on the device (BASELINE config 3, an extension): the arg-max window centres of this level predicted
+// from the surface results of the level above -- offsets from the surface centre scale with the surface size, rounded half
+// away from zero (kcc_pyramid.cpp predict()), wrapped cyclically.
+__device__ __forceinline__ int predict_idx(int idx, int n_from, int n_to) {
+    const double off = (double)(idx - n_from / 2) * (double)n_to / (double)n_from;
+    long p = n_to / 2 + lround(off);
+    p %= n_to; if (p < 0) p += n_to;
+    return (int)p;
+}
+__global__ void k_predict_windows(const SurfaceResult* __restrict__ rot, const SurfaceResult* __restrict__ trans, int n,
+                                  int PDu, int PCu, int Hu, int Wu, int PD, int PC, int H, int W,
+                                  int* __restrict__ wrr, int* __restrict__ wrc, int* __restrict__ wtr, int* __restrict__ wtc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int ri = rot[i].idx, ti = trans[i].idx;
+    wrr[i] = predict_idx(ri % PDu, PDu, PD); wrc[i] = predict_idx(ri / PDu, PCu, PC);
+    wtr[i] = predict_idx(ti % Hu, Hu, H);    wtc[i] = predict_idx(ti / Hu, Wu, W);
+}
+void launch_predict_windows(hipStream_t s, const SurfaceResult* rot, const SurfaceResult* trans, int n, int PDu, int PCu, int Hu, int Wu,
+                            int PD, int PC, int H, int W, int* wrr, int* wrc, int* wtr, int* wtc) {
+    hipLaunchKernelGGL(k_predict_windows, dim3((n + 63) / 64), dim3(64), 0, s, rot, trans, n, PDu, PCu, Hu, Wu, PD, PC, H, W, wrr, wrc, wtr, wtc);
+}
+
 // RemoveZeroComponent (correlation_flow.cc:79-87) on the shifted plane S: p(r,c) lives at S[(c+W/2)%W][(r+H/2)%H].
 //   column c=0 (all r):  (p(r,1) + p(r,W-1))/2   -- reads the ORIGINAL columns 1 and W-1, so it runs first
 //   row r=0 (c != 0):    (p(1,c) + p(H-1,c))/2

@@ -5,12 +5,14 @@
 //   the coarsest level runs the plain KCC pose (small-rotation mode); every finer level runs it with the arg-max of
 //   both correlation surfaces restricted to the (2R+1)^2 cyclic window around the peak predicted by the level above
 //   (rotation surface: also around the 180-degree mirror row -- its source is point-symmetric).
+//   A peak at index idx of a surface of size n_from predicts index n_to/2 + lround((idx - n_from/2) * n_to / n_from)
+//   (cyclic) on the finer surface; the prediction runs on the device (k_predict_windows), so the levels chain without
+//   a host round trip and their streams overlap.
 // One nik_ctx per level; host code only (the kernels are the ordinary ones plus the windowed arg-max).
 #include "../../include/nislam_kcc.h"
 
 #include <hip/hip_runtime_api.h>
 
-#include <cmath>
 #include <vector>
 
 struct nik_pyramid {
@@ -19,19 +21,6 @@ struct nik_pyramid {
     std::vector<int> h, w, pd, pc;
     std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer)
 };
-
-namespace {
-
-// surface index of level `to` predicted from the peak index `idx` (0 <= idx < n_from) of level `from`: offsets from the
-// surface centre scale with the surface size
-int predict(int idx, int n_from, int n_to) {
-    const double off = (double)(idx - n_from / 2) * (double)n_to / (double)n_from;
-    long p = n_to / 2 + std::lround(off);
-    p %= n_to; if (p < 0) p += n_to;
-    return (int)p;
-}
-
-}  // namespace
 
 extern "C" {
 
@@ -82,32 +71,31 @@ int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uin
     int rc;
     std::vector<const uint8_t*> key(L), cur(L);
     key[0] = d_key; cur[0] = d_cur;
+    // every level's frames first: level l is the 2x2 box filter of level l - 1, produced on level l - 1's stream (its
+    // geometry), and level l's streams wait for it.  From here on nothing returns to the host until the finest level has
+    // been enqueued.
     for (int l = 1; l < L; ++l) {
-        if ((rc = nik_downsample_u8_dev(p->ctx[l - 1], n, key[l - 1], p->d_key[l])) ||
-            (rc = nik_downsample_u8_dev(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l]))) return rc;
+        if ((rc = nik_downsample_u8_async(p->ctx[l - 1], n, key[l - 1], p->d_key[l])) ||
+            (rc = nik_downsample_u8_async(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l])) ||
+            (rc = nik_wait_for(p->ctx[l], p->ctx[l - 1]))) return rc;
         key[l] = p->d_key[l]; cur[l] = p->d_cur[l];
     }
     std::vector<nik_frame> ks(n), cs(n);
     for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; }
-    std::vector<int32_t> centers(4 * (size_t)n);
+    // key spectra of every level (independent of each other: the levels' streams overlap)
+    for (int l = L - 1; l >= 0; --l) if ((rc = nik_intermedium_batch_dev(p->ctx[l], n, key[l], ks.data()))) return rc;
+    // coarsest level: plain KCC; finer levels: windows predicted on the device from the level above
     for (int l = L - 1; l >= 0; --l) {
         nik_ctx* c = p->ctx[l];
         nik_pose_result* out = res + (size_t)l * n;
-        if ((rc = nik_intermedium_batch_dev(c, n, key[l], ks.data()))) return rc;
         if (l == L - 1) {
-            if ((rc = nik_track_batch_dev(c, n, cur[l], ks.data(), cs.data(), 1, out, 1))) return rc;
+            if ((rc = nik_track_batch_dev(c, n, cur[l], ks.data(), cs.data(), 1, out, 0))) return rc;
         } else {
-            const nik_pose_result* up = res + (size_t)(l + 1) * n;
-            for (int i = 0; i < n; ++i) {
-                centers[4 * i + 0] = predict(up[i].rot_row, p->pd[l + 1], p->pd[l]);
-                centers[4 * i + 1] = predict(up[i].rot_col, p->pc[l + 1], p->pc[l]);
-                centers[4 * i + 2] = predict(up[i].trans_row[0], p->h[l + 1], p->h[l]);
-                centers[4 * i + 3] = predict(up[i].trans_col[0], p->w[l + 1], p->w[l]);
-            }
             if ((rc = nik_intermedium_batch_dev(c, n, cur[l], cs.data())) ||
-                (rc = nik_pose_batch_window(c, n, ks.data(), cs.data(), centers.data(), radius, out))) return rc;
+                (rc = nik_pose_batch_chained(c, n, ks.data(), cs.data(), p->ctx[l + 1], radius, out, 0))) return rc;
         }
     }
+    for (int l = 0; l < L; ++l) if ((rc = nik_synchronize(p->ctx[l]))) return rc;
     return NIK_OK;
 }
 

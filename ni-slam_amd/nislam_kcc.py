@@ -30,7 +30,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
-           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats",
+           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
            "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
@@ -190,6 +190,7 @@ def load():
         L.nik_tracker_push_u8.argtypes = [P, P, I, P]
         L.nik_tracker_keyframes.argtypes = [P, P, I, P]
         L.nik_profile_read.argtypes = [P, P, I, P]
+        L.nik_set_graphs.argtypes = [P, I]
         L.nik_set_residual_stats.argtypes = [P, I]
         L.nik_residual_stats.argtypes = [P, P]
         L.nik_residual_stats_dev.argtypes = [P, P, P]
@@ -311,6 +312,9 @@ class CorrelationFlow:
                 self._L.nik_destroy(self._ctx)
             self._ctx = None
 
+    def set_graphs(self, max_pairs):
+        self._chk(self._L.nik_set_graphs(self._ctx, int(max_pairs)))
+
     # ---- residual statistics of the latest batch, reduced on the device ---------------------
     def set_residual_stats(self, on=True):
         self._chk(self._L.nik_set_residual_stats(self._ctx, int(bool(on))))
@@ -431,13 +435,17 @@ class CorrelationFlow:
     def downsample_u8_dev(self, d_in_ptr, n, d_out_ptr):
         self._chk(self._L.nik_downsample_u8_dev(self._ctx, int(n), C.c_void_p(int(d_in_ptr)), C.c_void_p(int(d_out_ptr))))
 
-    def match(self, query, cands):
+    def match(self, query, cands, raw=False):
+        """raw: hand back the ctypes result array as it is (timing loops: converting thousands of results to dicts costs
+        more than the search)"""
         cands = _i32(cands)
         n = len(cands)
         res = (NikPoseResult * max(n, 1))()
         best, best_res = C.c_int(-1), NikPoseResult()
         self._chk(self._L.nik_match(self._ctx, int(query), n, _p(cands), C.addressof(best), C.cast(res, C.c_void_p),
                                     C.addressof(best_res)))
+        if raw:
+            return best.value, res, best_res
         return best.value, [res[i].as_dict() for i in range(n)], best_res.as_dict()
 
     def match_topk(self, query, cands, k):

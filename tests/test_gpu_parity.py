@@ -449,3 +449,34 @@ def test_kzz_cache_same_results(kernel):
     cf.set_kzz_cache(False)
     _same_registration(cf.pose(0, n + 1, True)[2], a)
     cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_graph_replay_gives_identical_results(geom):
+    """nik_set_graphs: small stored-frame batches replayed as one hipGraph -- same results as separate launches, for every
+    batch size up to the limit, both ComputePose modes, with and without the Kzz cache and the residual statistics"""
+    n = 8
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 1700)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    cf.set_residual_stats(True)
+    for cache in (False, True):
+        cf.set_kzz_cache(cache)
+        for small_rot in (True, False):
+            for m in (1, 2, 5, 8):
+                ks, cs = list(range(m)), list(range(n, n + m))
+                cf.set_graphs(0)
+                want = cf.pose_batch(ks, cs, small_rot)
+                st = cf.residual_stats()
+                cf.set_graphs(8)
+                for rep in range(3):                      # 1st: ordinary (shape seen), 2nd: captured + replayed, 3rd: replayed
+                    assert cf.pose_batch(ks, cs, small_rot) == want, (cache, small_rot, m, rep)
+                    assert np.array_equal(cf.residual_stats(), st)
+                # a different set of slots through the same captured graph
+                ks2, cs2 = list(range(n - m, n)), list(range(2 * n - m, 2 * n))
+                got = cf.pose_batch(ks2, cs2, small_rot)
+                cf.set_graphs(0)
+                assert got == cf.pose_batch(ks2, cs2, small_rot)
+    cf.close()
