@@ -341,8 +341,12 @@ def test_other_reference_geometries(H, W):
         cf.intermedium_u8(curs[i], n + i)
     res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), True)
     poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True, nthreads=n)
+    # PSR = (peak - mean) / std of a surface whose float32 deviation from the exact response is itself a few 1e-3 of the peak
+    # (tests/test_gpu_wide.py measures it at 640x480); at 1600x1200 a PSR near 420 means std ~ 2.4e-3 of the peak, so the
+    # noise is a visible part of std: indices and poses stay exact, the PSR tolerance is 5e-3 there
+    rtol = 5e-3 if H * W > 1000000 else 2e-3
     for i in range(n):
-        ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], 720)
+        ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], 720, psr_rtol=rtol)
         assert ok, "pair %d %s: %s" % (i, motions[i], msg)
     cf.close()
 

@@ -17,7 +17,7 @@ import csv, glob, json, collections, re, shutil, os
 out, tag, R = "$OUT", "$TAG", "$R"
 st = glob.glob(out + "/prof_%s/stats/**/*kernel_stats.csv" % tag, recursive=True)
 if st: shutil.copy(st[0], out + "/%s_kernel_stats.csv" % tag)
-AF = {0: "plane", 1: "rot", 2: "polar"}; AI = {0: "real", 1: "kernel_fwd", 2: "argmax", 3: "kernel_fwd", 4: "kernel_fwd", 5: "shifted"}
+AF = {0: "plane", 1: "rot", 3: "u8", 4: "rot8", 5: "polar", 6: "polar", 7: "polar"}; AI = {0: "real", 1: "kernel_fwd", 2: "argmax", 3: "kernel_fwd", 4: "kernel_fwd", 5: "shifted"}
 BM = {0: "fwd", 1: "fwd_abs_inv", 2: "mul_inv", 3: "fwd_mul_inv", 4: "solve_inv", 5: "inv", 6: "zz_inv", 7: "mul_inv_x", 8: "fwd_mul_inv_x", 9: "solve_cached"}
 def stage(k):
     m = re.search(r"(kA_fwd|kA_inv|kB)<(\d+), (\d+)>", k)
