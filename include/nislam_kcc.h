@@ -192,6 +192,9 @@ typedef struct {
     double  cf_pose[3];            /* _current_cf_pose (image plane, pixels)                                  */
     double  robot_pose[3];         /* _current_pose                                                           */
     double  distance;              /* _distance: accumulated travel of the keyframes so far (SetFrameDistance) */
+    int32_t optimized;             /* 1: this keyframe triggered CheckAndOptimize and the pose graph was optimised;
+                                      cf_pose / robot_pose are the values after UpdateValueAfterLoop                */
+    int32_t reserved_;
 } nik_track_output;
 
 /* replaces MapBuilder::MapBuilder's tracking members (map_builder.cc:18-28); the tracker borrows ctx */
@@ -236,6 +239,8 @@ void nik_map_destroy(nik_map* m);
  * NULL = never set, GetFrameDistance then reports -1).  `slot` is the device slot holding the keyframe's spectra. */
 int  nik_map_add_frame(nik_map* m, int frame_id, nik_frame slot, const double pose[3], const double* distance);
 int  nik_map_size(const nik_map* m);
+/* Map::UpdatePoses (map.cc:73-79): new poses for the listed frames (the grid cells stay as inserted, as in the reference) */
+int  nik_map_update_poses(nik_map* m, int n, const int32_t* frame_ids, const double* poses /*[n][3]*/);
 /* the frames LoopClosure::FindLoopClosure would call ComputePose on for keyframe cur_frame_id (already added):
  * all frames (prior_pose NULL, loop_closure.cc:10-15) or those in the 3 x 3 grid cells around prior_pose
  * (:17-33), minus the frame-gap and travel-distance filters (:43-53). */
@@ -246,10 +251,18 @@ int  nik_map_find_loop(nik_map* m, int cur_frame_id, const double* prior_pose, n
 
 /* MapBuilder's map side for the tracker (map_builder.cc:61-65,168-178): with a map attached (before the first frame;
  * borrowed), every keyframe is added to it with its robot pose and accumulated distance, and -- if to_find_loop --
- * searched for a loop closure around that pose; found loops accumulate like MapBuilder::_loop_matches
- * (relative_pose already passed through ConvertCenterToPrincipal).  Pose-graph optimisation is out of scope. */
+ * searched for a loop closure around that pose.  Loops found at consecutive keyframes accumulate like
+ * MapBuilder::_loop_matches (relative_pose already passed through ConvertCenterToPrincipal); the first keyframe WITHOUT
+ * a loop runs CheckAndOptimize (map_builder.cc:108-116): with >= 2 accumulated loops their edges are added, the pose
+ * graph of all keyframes (KCC edges between consecutive keyframes + loop edges, identity information) is optimised
+ * (nik_pose_graph_optimize), the map's and the tracker's poses are replaced (Map::UpdatePoses, UpdateValueAfterLoop) and
+ * that frame's output carries optimized = 1 -- the caller then refreshes its occupancy map (nik_tracker_poses ->
+ * nik_stitcher_recompute, MapStitcher::RecomputeOccupancy); the accumulated loops are cleared either way. */
 int  nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop);
-int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);
+int  nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n);       /* every loop found so far */
+int  nik_tracker_pending_loops(const nik_tracker* t);                                       /* MapBuilder::_loop_matches.size() */
+/* robot poses of all keyframes (ascending frame id), as last written by the tracker or the optimiser */
+int  nik_tracker_poses(const nik_tracker* t, int32_t* frame_ids, double* poses /*[cap][3]*/, int cap, int* n);
 
 /* ---- MapStitcher (src/map_stitcher.cc, include/map_stitcher.h): occupancy map of the key frames -----------------
  * Cells are cell_size x cell_size int32 planes (data, weight), row-major [y in cell][x in cell], addressed by the
@@ -306,6 +319,11 @@ typedef struct {
 /* poses: n_poses x (x, y, yaw), updated in place; ids: their frame ids (must contain 0); max_iterations <= 0: 300. */
 int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* poses, int n_constraints,
                             const nik_pg_constraint* constraints, int max_iterations, nik_pg_summary* summary);
+
+/* the tracker's pose graph: Map::_edges as OptimizeMap would feed them to the solver (robot units, identity information;
+ * types[i]: 0 = KCC edge between consecutive keyframes, 1 = loop edge), and how often CheckAndOptimize has optimised */
+int  nik_tracker_edges(const nik_tracker* t, nik_pg_constraint* out, int32_t* types, int cap, int* n);
+int  nik_tracker_optimizations(const nik_tracker* t, nik_pg_summary* last /* may be NULL */);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

@@ -94,6 +94,16 @@ int nik_map_add_frame(nik_map* m, int frame_id, nik_frame slot, const double pos
 
 int nik_map_size(const nik_map* m) { return m ? (int)m->frames.size() : 0; }
 
+// Map::UpdatePoses (map.cc:73-79): poses only -- the grid keeps the cells the frames were inserted into, as the reference's does
+int nik_map_update_poses(nik_map* m, int n, const int32_t* frame_ids, const double* poses) {
+    if (!m || n < 0 || (n > 0 && (!frame_ids || !poses))) return NIK_ERR_INVALID_ARG;
+    for (int i = 0; i < n; ++i) {
+        auto it = m->frames.find(frame_ids[i]);
+        if (it != m->frames.end()) for (int k = 0; k < 3; ++k) it->second.pose[k] = poses[3 * i + k];
+    }
+    return NIK_OK;
+}
+
 int nik_map_candidates(const nik_map* m, int cur_frame_id, const double* prior_pose, int* frame_ids, int cap, int* n) {
     if (!m || !n) return NIK_ERR_INVALID_ARG;
     std::vector<int> ids;

@@ -52,23 +52,90 @@ struct nik_tracker {
     int spec_depth = 8;                      // frames registered speculatively per batch (adapts to the keyframe spacing)
     nik_map* map = nullptr;                  // optional (borrowed): keyframes are added to it and searched for loops
     int to_find_loop = 0;
-    std::vector<nik_loop_result> loops;      // MapBuilder::_loop_matches (never cleared here: no optimiser consumes them)
-    int map_rc = NIK_OK;                     // first error of a map / loop-closure call inside a push
+    // MapBuilder::_loop_matches: loops found at CONSECUTIVE keyframes; a keyframe without a loop triggers CheckAndOptimize
+    // (optimise when >= 2 have accumulated) and clears them (map_builder.cc:66-67,108-116)
+    std::vector<nik_loop_result> loops;
+    std::vector<nik_loop_result> all_loops;  // every loop ever found (diagnostics: nik_tracker_loops)
+    // Map::_edges (KCC edges between consecutive keyframes, loop edges) and the keyframes' robot poses
+    struct EdgeRec { int from, to, type; double T[3]; };     // type 0 = KCC, 1 = Loop; T in camera units (edge->_T)
+    std::vector<EdgeRec> edges;
+    std::vector<int> kf_ids; std::vector<V3> kf_poses;       // Map::_frames: id -> pose (ascending id)
+    int optimizations = 0; nik_pg_summary last_summary{};
+    int map_rc = NIK_OK;                     // first error of a map / loop-closure / optimiser call inside a push
 
-    // the map side of AddNewInput for a frame that became a keyframe (map_builder.cc:61-65,168-178)
-    void keyframe_to_map(const nik_track_output& o, bool search) {
-        if (!map || map_rc) return;
-        if ((map_rc = nik_map_add_frame(map, o.frame_id, o.slot, o.robot_pose, &o.distance))) return;
-        if (!search || !to_find_loop) return;
-        nik_loop_result lr;
-        if ((map_rc = nik_map_find_loop(map, o.frame_id, o.robot_pose, &lr))) return;     // prior = _current_pose (:169)
-        if (lr.found) {
-            V3 rp; for (int k = 0; k < 3; ++k) rp[k] = lr.relative_pose[k];
-            rp = center_to_principal(rp);                                                  // :171
-            for (int k = 0; k < 3; ++k) lr.relative_pose[k] = rp[k];
-            loops.push_back(lr);
+    // the map side of AddNewInput for a frame that became a keyframe (map_builder.cc:60-67,168-178): AddFrame,
+    // SetFrameDistance, FindLoopClosure, and -- when this keyframe found no loop -- CheckAndOptimize.  Returns whether the
+    // poses were optimised (the caller then refreshes its current pose: UpdateValueAfterLoop).
+    bool keyframe_to_map(const nik_track_output& o, bool search) {
+        kf_ids.push_back(o.frame_id);
+        V3 rp0; for (int k = 0; k < 3; ++k) rp0[k] = o.robot_pose[k];
+        kf_poses.push_back(rp0);
+        if (!map || map_rc) return false;
+        if ((map_rc = nik_map_add_frame(map, o.frame_id, o.slot, o.robot_pose, &o.distance))) return false;
+        if (!search) return false;
+        bool found = false;
+        if (to_find_loop) {
+            nik_loop_result lr;
+            if ((map_rc = nik_map_find_loop(map, o.frame_id, o.robot_pose, &lr))) return false;     // prior = _current_pose (:169)
+            if (lr.found) {
+                V3 rp; for (int k = 0; k < 3; ++k) rp[k] = lr.relative_pose[k];
+                rp = center_to_principal(rp);                                                  // :171
+                for (int k = 0; k < 3; ++k) lr.relative_pose[k] = rp[k];
+                loops.push_back(lr); all_loops.push_back(lr);
+                found = true;
+            }
         }
+        return found ? false : check_and_optimize();
     }
+
+    // MapBuilder::CheckAndOptimize (map_builder.cc:108-116): AddLoopEdges (:180-189), OptimizeMap (:195-271), Map::UpdatePoses
+    bool check_and_optimize() {
+        bool done = false;
+        if (loops.size() >= 2) {
+            for (const nik_loop_result& lm : loops) {                                           // AddLoopEdges
+                V3 ip; for (int k = 0; k < 3; ++k) ip[k] = lm.relative_pose[k];
+                const V3 cam = image_plane_to_camera(ip);
+                edges.push_back({ lm.loop_frame_id, lm.cur_frame_id, 1, { cam[0], cam[1], cam[2] } });
+            }
+            // OptimizeMap: every frame's pose, every KCC / loop edge as a constraint in robot units, identity information
+            std::vector<int32_t> ids(kf_ids.begin(), kf_ids.end());
+            std::vector<double> poses(3 * kf_poses.size());
+            for (size_t i = 0; i < kf_poses.size(); ++i) for (int k = 0; k < 3; ++k) poses[3 * i + k] = kf_poses[i][k];
+            std::vector<nik_pg_constraint> cons;
+            for (const EdgeRec& e : edges) {
+                if (!std::binary_search(kf_ids.begin(), kf_ids.end(), e.from) || !std::binary_search(kf_ids.begin(), kf_ids.end(), e.to)) continue;
+                V3 t; for (int k = 0; k < 3; ++k) t[k] = e.T[k];
+                const V3 r = camera_to_robot(t);
+                nik_pg_constraint c{};
+                c.id_begin = e.from; c.id_end = e.to; c.x = r[0]; c.y = r[1]; c.yaw_radians = r[2];
+                c.information[0] = c.information[4] = c.information[8] = 1.0;
+                cons.push_back(c);
+            }
+            const int rc = nik_pose_graph_optimize((int)ids.size(), ids.data(), poses.data(), (int)cons.size(), cons.data(), 0, &last_summary);
+            if (rc) { map_rc = rc; }
+            else {
+                for (size_t i = 0; i < kf_poses.size(); ++i) for (int k = 0; k < 3; ++k) kf_poses[i][k] = poses[3 * i + k];
+                if (map) map_rc = nik_map_update_poses(map, (int)ids.size(), ids.data(), poses.data());      // Map::UpdatePoses (map.cc:73-79)
+                optimizations += 1; done = true;
+            }
+        }
+        loops.clear();
+        return done;
+    }
+
+    // Camera::ConvertRobotPoseToCamera (camera.cc:213-224) and ConvertCameraPoseToImagePlane (:178-195)
+    V3 robot_to_camera(const V3& r) const {
+        const double* E = cfg.extrinsics;
+        const double det = E[0] * (E[4] * E[8] - E[5] * E[7]) - E[1] * (E[3] * E[8] - E[5] * E[6]) + E[2] * (E[3] * E[7] - E[4] * E[6]);
+        const double inv[9] = { (E[4] * E[8] - E[5] * E[7]) / det, (E[2] * E[7] - E[1] * E[8]) / det, (E[1] * E[5] - E[2] * E[4]) / det,
+                                (E[5] * E[6] - E[3] * E[8]) / det, (E[0] * E[8] - E[2] * E[6]) / det, (E[2] * E[3] - E[0] * E[5]) / det,
+                                (E[3] * E[7] - E[4] * E[6]) / det, (E[1] * E[6] - E[0] * E[7]) / det, (E[0] * E[4] - E[1] * E[3]) / det };
+        V3 c;
+        for (int i = 0; i < 3; ++i) c[i] = inv[3 * i] * r[0] + inv[3 * i + 1] * r[1] + inv[3 * i + 2] * r[2];
+        c[0] /= cfg.height; c[1] /= cfg.height;
+        return c;
+    }
+    V3 camera_to_image_plane(const V3& c) const { V3 p; p[0] = cfg.fx * c[0]; p[1] = cfg.fy * c[1]; p[2] = c[2]; return p; }
 
     // Camera::ConvertCenterToPrincipal (src/camera.cc:148-158)
     V3 center_to_principal(const V3& c) const {
@@ -139,10 +206,21 @@ bool apply_result(nik_tracker* t, const nik_pose_result& r, nik_frame slot, nik_
     for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cur_cf[k]; o.robot_pose[k] = cur_pose[k]; }
     o.inserted = insert; o.distance = t->distance;
     if (insert) {
+        // AddCFEdge() (:140-144): KCC edge last keyframe -> this frame, relative pose in camera units
+        const V3 rel_real = compute_relative_pose(t->last_cf_real_pose, cur_real);
+        t->edges.push_back({ t->key_frame_id, o.frame_id, 0, { rel_real[0], rel_real[1], rel_real[2] } });
+        o.slot = slot;
+        if (t->keyframe_to_map(o, true)) {
+            // UpdateValueAfterLoop() (:273-277): the optimiser moved this frame
+            cur_pose = t->kf_poses.back();
+            cur_real = t->robot_to_camera(cur_pose);
+            cur_cf = t->camera_to_image_plane(cur_real);
+            for (int k = 0; k < 3; ++k) { o.cf_pose[k] = cur_cf[k]; o.robot_pose[k] = cur_pose[k]; }
+            o.optimized = 1;
+        }
         // UpdateIntermedium() (:99-106): this frame is the new keyframe
         t->last_cf_pose = cur_cf; t->last_cf_real_pose = cur_real; t->last_pose = cur_pose;
-        t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot); o.slot = slot;
-        t->keyframe_to_map(o, true);
+        t->key_slot = slot; t->key_frame_id = o.frame_id; t->keyframes.push_back(slot);
     }
     return insert;
 }
@@ -175,9 +253,41 @@ int nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop) {
 
 int nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* n) {
     if (!t || !n) return NIK_ERR_INVALID_ARG;
-    *n = (int)t->loops.size();
-    for (int i = 0; i < *n && i < cap && out; ++i) out[i] = t->loops[i];
+    *n = (int)t->all_loops.size();
+    for (int i = 0; i < *n && i < cap && out; ++i) out[i] = t->all_loops[i];
     return NIK_OK;
+}
+
+int nik_tracker_pending_loops(const nik_tracker* t) { return t ? (int)t->loops.size() : 0; }
+
+int nik_tracker_poses(const nik_tracker* t, int32_t* frame_ids, double* poses, int cap, int* n) {
+    if (!t || !n) return NIK_ERR_INVALID_ARG;
+    *n = (int)t->kf_ids.size();
+    for (int i = 0; i < *n && i < cap; ++i) {
+        if (frame_ids) frame_ids[i] = t->kf_ids[i];
+        if (poses) for (int k = 0; k < 3; ++k) poses[3 * i + k] = t->kf_poses[i][k];
+    }
+    return NIK_OK;
+}
+
+int nik_tracker_edges(const nik_tracker* t, nik_pg_constraint* out, int32_t* types, int cap, int* n) {
+    if (!t || !n) return NIK_ERR_INVALID_ARG;
+    *n = (int)t->edges.size();
+    for (int i = 0; i < *n && i < cap; ++i) {
+        const auto& e = t->edges[i];
+        V3 T; for (int k = 0; k < 3; ++k) T[k] = e.T[k];
+        const V3 r = t->camera_to_robot(T);
+        if (out) { nik_pg_constraint c{}; c.id_begin = e.from; c.id_end = e.to; c.x = r[0]; c.y = r[1]; c.yaw_radians = r[2];
+                   c.information[0] = c.information[4] = c.information[8] = 1.0; out[i] = c; }
+        if (types) types[i] = e.type;
+    }
+    return NIK_OK;
+}
+
+int nik_tracker_optimizations(const nik_tracker* t, nik_pg_summary* last) {
+    if (!t) return 0;
+    if (last) *last = t->last_summary;
+    return t->optimizations;
 }
 
 int nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n) {

@@ -30,7 +30,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
-           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
+           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
            "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
@@ -68,12 +68,12 @@ class NikTrackerConfig(C.Structure):
 class NikTrackOutput(C.Structure):
     _fields_ = [("frame_id", C.c_int32), ("inserted", C.c_int32), ("good_tracking", C.c_int32), ("key_frame_id", C.c_int32),
                 ("slot", C.c_int32), ("response", C.c_double * 3), ("cf_pose", C.c_double * 3), ("robot_pose", C.c_double * 3),
-                ("distance", C.c_double)]
+                ("distance", C.c_double), ("optimized", C.c_int32), ("reserved_", C.c_int32)]
 
     def as_dict(self):
         return dict(frame_id=self.frame_id, inserted=bool(self.inserted), good_tracking=bool(self.good_tracking),
                     key_frame_id=self.key_frame_id, slot=self.slot, response=list(self.response), cf_pose=list(self.cf_pose),
-                    robot_pose=list(self.robot_pose), distance=self.distance)
+                    robot_pose=list(self.robot_pose), distance=self.distance, optimized=bool(self.optimized))
 
 
 class NikLoopConfig(C.Structure):
@@ -140,6 +140,11 @@ def load():
         L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
         L.nik_tracker_attach_map.argtypes = [P, P, I]
         L.nik_tracker_loops.argtypes = [P, P, I, P]
+        L.nik_tracker_pending_loops.argtypes = [P]
+        L.nik_tracker_poses.argtypes = [P, P, P, I, P]
+        L.nik_tracker_edges.argtypes = [P, P, P, I, P]
+        L.nik_tracker_optimizations.argtypes = [P, P]
+        L.nik_map_update_poses.argtypes = [P, I, P, P]
         L.nik_pose_graph_optimize.argtypes = [I, P, P, I, P, I, P]
         L.nik_stitcher_create.argtypes = [P, I, P]
         L.nik_stitcher_destroy.argtypes = [P]
@@ -658,6 +663,32 @@ class Tracker:
         out = (NikLoopResult * max(n.value, 1))()
         self._L.nik_tracker_loops(self._t, C.cast(out, C.c_void_p), n.value, C.addressof(n))
         return [out[i].as_dict() for i in range(n.value)]
+
+    def pending_loops(self):
+        return self._L.nik_tracker_pending_loops(self._t)
+
+    def poses(self):
+        """robot poses of all keyframes: (ids, (n, 3) array) as last written by the tracker / the optimiser"""
+        n = C.c_int(0)
+        self._L.nik_tracker_poses(self._t, None, None, 0, C.addressof(n))
+        ids = np.zeros(max(n.value, 1), np.int32); poses = np.zeros((max(n.value, 1), 3), np.float64)
+        self._L.nik_tracker_poses(self._t, _p(ids), _p(poses), n.value, C.addressof(n))
+        return ids[: n.value].tolist(), poses[: n.value]
+
+    def edges(self):
+        """Map::_edges as OptimizeMap feeds them to the solver: list of (id_begin, id_end, x, y, yaw, information, type)"""
+        n = C.c_int(0)
+        self._L.nik_tracker_edges(self._t, None, None, 0, C.addressof(n))
+        cons = (NikPgConstraint * max(n.value, 1))(); types = np.zeros(max(n.value, 1), np.int32)
+        self._L.nik_tracker_edges(self._t, C.cast(cons, C.c_void_p), _p(types), n.value, C.addressof(n))
+        return [(cons[i].id_begin, cons[i].id_end, cons[i].x, cons[i].y, cons[i].yaw_radians, np.array(cons[i].information).reshape(3, 3), int(types[i]))
+                for i in range(n.value)]
+
+    def optimizations(self):
+        sm = NikPgSummary()
+        k = self._L.nik_tracker_optimizations(self._t, C.addressof(sm))
+        return k, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
+                       initial_cost=sm.initial_cost, final_cost=sm.final_cost)
 
     def keyframes(self):
         slots = np.zeros(self._flow.max_frames, np.int32)

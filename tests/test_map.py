@@ -23,7 +23,7 @@ def test_struct_sizes():
     N = nik()
     assert ctypes.sizeof(N.NikLoopConfig) == 8 + 4 + 4 + 8 + 8 + 8
     assert ctypes.sizeof(N.NikLoopResult) == 5 * 4 + 4 + 3 * 8 + 3 * 8
-    assert ctypes.sizeof(N.NikTrackOutput) == 5 * 4 + 4 + 10 * 8
+    assert ctypes.sizeof(N.NikTrackOutput) == 5 * 4 + 4 + 10 * 8 + 2 * 4
 
 
 def test_candidates_random_walk():

@@ -89,3 +89,53 @@ def test_full_pipeline_closes_a_loop():
     cells_after = {c: st.read_cell(*c)[1].sum() for c in st.cells()}
     assert sum(cells_before.values()) == sum(cells_after.values()) == len(ids) * H * W        # every pixel of every key frame lands somewhere
     trk.close(); kmap.close(); st.close(); flow.close()
+
+
+@pytest.mark.gpu
+def test_tracker_runs_check_and_optimize_like_map_builder():
+    """MapBuilder::CheckAndOptimize in the C++ tracker (map_builder.cc:66-67,108-116,180-277): loops found at consecutive key
+    frames accumulate; the first key frame without a loop adds their edges, optimises the pose graph, rewrites the poses
+    (Map::UpdatePoses, UpdateValueAfterLoop) and clears the matches."""
+    import torch
+    N = nik()
+    geom = SMALL; H, W = geom["H"], geom["W"]
+    f, height = 600.0 * W / 640, 0.1
+    cv = synth.canvas(61, H, W)
+    # out, back beside the outbound track (loops at consecutive key frames), then away into fresh ground (no loop)
+    path = [(2 * i, 3 * i) for i in range(10)] + [(2 * i, 3 * i + 1) for i in range(8, -1, -1)] + [(-3 * i, -2 * i) for i in range(1, 7)]
+    frames = np.stack([synth.window(cv, H, W, dy, dx) for dy, dx in path])
+    n = len(frames)
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    flow = N.CorrelationFlow(cfg, H, W, max_batch=6, max_frames=n + 8)
+    tc = N.tracker_config(fx=f, fy=f, cx=W / 2, cy=H / 2, height=height, max_distance=0.002, max_angle=0.02, lower_response_thr=8.0, upper_response_thr=9.0)
+    trk = N.Tracker(flow, tc)
+    kmap = N.KeyframeMap(flow, N.loop_config(grid_scale=0.01, frame_gap_thr=4, distance_thr=0.004, position_response_thr=12.0, angle_response_thr=12.0))
+    trk.attach_map(kmap, True)
+    d = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+    outs = []
+    for b in range(0, n, 6):
+        outs += trk.push_dev(d[b:b + min(6, n - b)].data_ptr(), min(6, n - b))
+    keys = [o for o in outs if o["inserted"]]
+    loops = trk.loops()
+    nopt, sm = trk.optimizations()
+    opt_frames = [o["frame_id"] for o in outs if o["optimized"]]
+    assert len(loops) >= 2 and nopt >= 1 and len(opt_frames) == nopt and sm["termination"] in (0, 1)
+    assert trk.pending_loops() == 0 or keys[-1]["frame_id"] in [l["cur_frame_id"] for l in loops]
+    edges = trk.edges()
+    n_loop_edges = sum(1 for e in edges if e[6] == 1)
+    assert sum(1 for e in edges if e[6] == 0) == len(keys) - 1            # one KCC edge per key frame after the first
+    assert 2 <= n_loop_edges <= len(loops)                                # loops still pending at the end have no edge yet
+    # every optimisation consumed at least two consecutive loops, none of them twice
+    cur_ids = [l["cur_frame_id"] for l in loops]
+    assert len(set(cur_ids)) == len(cur_ids)
+    # the optimised poses are a fixed point of the solver on the edge set of the LAST optimisation (later key frames only
+    # append dead-reckoned poses and KCC edges, which cost nothing)
+    ids, poses = trk.poses()
+    assert ids == [o["frame_id"] for o in keys]
+    again, sm2 = N.pose_graph_optimize(ids, poses, [e[:6] for e in edges])
+    assert np.abs(again - poses).max() < 1e-7 and sm2["final_cost"] <= sm2["initial_cost"] + 1e-18
+    # exact registrations of integer-pixel motion: the optimum is the ground truth itself
+    for k, o in enumerate(keys):
+        dy, dx = path[o["frame_id"]]
+        assert np.allclose(poses[k][:2], [height * dx / f, height * dy / f], atol=1e-8)
+    trk.close(); kmap.close(); flow.close()
