@@ -584,37 +584,6 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
         }
     }
-    if (SRC == SRC_U8 && !ABL(a, 1)) {
-        // ConvertMatToNormalizedArray (utils.cc:110-118) fused into the first FFT pass: the tile's 16 image columns are
-        // 16 bytes of every image row.  Rows are staged in LDS ([row][16 bytes]) and copied into the u8 frame store
-        // (the de-rotation of ComputePose reads the image from there); a thread then picks up its points as bytes.
-        const uint8_t* in = a.src8 + (size_t)item * a.src8_stride + x0;
-        uint8_t* keep = a.dst8 ? a.dst8 + (size_t)a.dst8_slot[item] * a.dst8_stride + x0 : nullptr;
-        uint4* st = reinterpret_cast<uint4*>(smem);
-        constexpr int ROWS = 2 * HH;
-#pragma unroll
-        for (int it = 0; it < (ROWS + C::NT - 1) / C::NT; ++it) {
-            const int r = tid + it * C::NT;
-            if (r < ROWS) {
-                const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)r * a.src8_pitch);
-                st[r] = v;
-                if (keep && !ABL(a, 64)) {
-                    *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch) = v;
-                    if (bx == 0) *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + a.cols) = v;   // wrap columns
-                }
-            }
-        }
-        __syncthreads();
-        if (j < D::MF) {
-            const uint8_t* sb = reinterpret_cast<const uint8_t*>(smem) + line;
-#pragma unroll
-            for (int q = 0; q < D::RF; ++q) {
-                const int m = j + q * D::MF;
-                vin[0][q] = make_float2(unit_u8(sb[32 * m]), unit_u8(sb[32 * m + 16]));
-            }
-        }
-        __syncthreads();                                     // staged rows consumed before the exchange overwrites them
-    }
     if (POLAR && !ABL(a, 1)) {
         // polar(fftshift(RemoveZeroComponent(p)))  (correlation_flow.cc:228-236).  The source pixels of the tile's
         // samples (A_LX radii x all angles = an annulus) are staged in LDS one angular segment at a time: the host lists,
@@ -788,6 +757,86 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
     }
     __syncthreads();
     if (!ABL(a, 2)) a_post_store<C>(lds, a.tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+}
+
+// ConvertMatToNormalizedArray (utils.cc:110-118) fused into the first FFT pass, persistent form: a workgroup transforms
+// `tpw` consecutive 16-column tiles of ONE image and fetches the rows of the next tile (two 16-byte loads per thread, held in
+// registers) while it transforms the current one, so the load latency -- which dominated the one-tile-per-workgroup form --
+// hides behind the FFT (measured: 0.137 -> 0.119 ms at two tiles per workgroup; more tiles per workgroup leave too few
+// workgroups).  The tile's 16 image columns are 16 bytes of every image row: rows are staged in LDS ([row][16 bytes])
+// and copied into the u8 frame store (the de-rotation of ComputePose reads the image from there); a thread then picks up
+// its first-pass points as bytes.
+#ifndef KCC_U8_TPW
+#define KCC_U8_TPW 2
+#endif
+template <int HH>
+__global__ __launch_bounds__(FCfg<HH>::NT, FCfg<HH>::WPS) void kA_fwd_u8(AArgs a, int tpw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
+    constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
+    constexpr int A_LX = C::LX, ROWS = 2 * HH, NR = (ROWS + C::NT - 1) / C::NT;
+    float2* lds = reinterpret_cast<float2*>(smem);
+    if (ABL(a, 8)) return;
+    int g, item;
+    xcd_coords((a.cols / A_LX) / tpw, a.n_items, g, item);           // groups of tpw tiles; an image's groups share an XCD
+    const uint8_t* in = a.src8 + (size_t)item * a.src8_stride;
+    uint8_t* keep = a.dst8 ? a.dst8 + (size_t)a.dst8_slot[item] * a.dst8_stride : nullptr;
+    uint4 cur[NR], nxt[NR];
+    auto fetch = [&](uint4 (&v)[NR], int x0, int tid) {
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int r = tid + it * C::NT;
+            if (r < ROWS && !ABL(a, 1)) v[it] = *reinterpret_cast<const uint4*>(in + (size_t)r * a.src8_pitch + x0);
+            else v[it] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    fetch(cur, g * tpw * A_LX, threadIdx.x);
+    for (int t = 0; t < tpw; ++t) {
+        const int bx = g * tpw + t, x0 = bx * A_LX;
+        // Everything per-thread is re-derived per tile from an opaque copy of the thread index, and the twiddle tables are
+        // re-read: hoisted out of the loop (which the compiler does eagerly) those values sit in ~60 VGPRs for the loop's
+        // whole length and push the kernel into scratch spills.
+        int tid = threadIdx.x;
+        const float2* tw_f = a.tw_f; const float2* tw_full = a.tw_full;
+        asm volatile("" : "+v"(tid), "+s"(tw_f), "+s"(tw_full));
+        const int line = tid / C::T, j = tid - line * C::T;
+        if (t + 1 < tpw) fetch(nxt, x0 + A_LX, tid);
+        uint4* st = reinterpret_cast<uint4*>(smem);
+#pragma unroll
+        for (int it = 0; it < NR; ++it) {
+            const int r = tid + it * C::NT;
+            if (r < ROWS) {
+                st[r] = cur[it];
+                if (keep && !ABL(a, 64)) {
+                    *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + x0) = cur[it];
+                    if (bx == 0) *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + a.cols) = cur[it];   // wrap columns
+                }
+            }
+        }
+        __syncthreads();
+        float2 vin[1][D::RF], vout[1][D::RL];
+        if (j < D::MF) {
+            const uint8_t* sb = reinterpret_cast<const uint8_t*>(smem) + line;
+#pragma unroll
+            for (int q = 0; q < D::RF; ++q) {
+                const int m = j + q * D::MF;
+                vin[0][q] = make_float2(unit_u8(sb[32 * m]), unit_u8(sb[32 * m + 16]));
+            }
+        }
+        __syncthreads();                                     // staged rows consumed before the exchange overwrites them
+        float2* const ex[1] = { lds + line * C::EPITCH };
+        if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, tw_f);
+        __syncthreads();                                     // exchange buffer fully consumed
+        if (j < D::ML) {
+#pragma unroll
+            for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
+        }
+        __syncthreads();
+        if (!ABL(a, 2)) a_post_store<C>(lds, tw_full, a.spec + (size_t)item * a.spec_stride, a.cols, x0, tid);
+        __syncthreads();                                     // natural buffer consumed before the next tile is staged
+#pragma unroll
+        for (int it = 0; it < NR; ++it) cur[it] = nxt[it];
+    }
 }
 
 // row r within `radius` (cyclically) of the window centre, or -- rotation surfaces, whose source is point-symmetric --
@@ -1064,13 +1113,25 @@ void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
+template <int HH> static void launchA_fwd_u8_t(hipStream_t s, int n_items, AArgs a) {
+    a.n_items = n_items;
+    const int nbx = a.cols / FCfg<HH>::LX;
+    int tpw = KCC_U8_TPW;
+    while (tpw > 1 && nbx % tpw) --tpw;                      // tiles per workgroup must divide the tiles of an image
+    dim3 grid((nbx / tpw) * n_items), block(FCfg<HH>::NT);
+    const size_t bytes = FCfg<HH>::BYTES;
+    static const bool big_lds = (FCfg<HH>::BYTES > 65536) &&
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_fwd_u8<HH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)FCfg<HH>::BYTES) == hipSuccess);
+    (void)big_lds;
+    hipLaunchKernelGGL((kA_fwd_u8<HH>), grid, block, bytes, s, a, tpw);
+}
 void launch_A_fwd_u8(hipStream_t s, int n_items, PlaneGeom g, Tables t, const uint8_t* src, size_t src_stride, int src_pitch,
                      uint8_t* keep, size_t keep_stride, int keep_pitch, const int* keep_slot, float2* dst, size_t dst_stride) {
     AArgs a = base_args(g, t);
     a.src8 = src; a.src8_stride = src_stride; a.src8_pitch = src_pitch;
     a.dst8 = keep; a.dst8_stride = keep_stride; a.dst8_pitch = keep_pitch; a.dst8_slot = keep_slot;
     a.spec = dst; a.spec_stride = dst_stride;
-#define CALL(HH) launchA_fwd_t<HH, SRC_U8>(s, n_items, a)
+#define CALL(HH) launchA_fwd_u8_t<HH>(s, n_items, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL
 }
@@ -1185,7 +1246,14 @@ template <int N, int MODE> struct BCfg {
     using P = PlanFor<N>;
     static constexpr int T = P::T;
     // exchange buffers per line: two for the modes that transform two planes at once, else one
-    static constexpr int NV = (MODE == 2 || MODE == 3 || MODE == 4) ? 2 : 1;
+    // SEQ: the two planes of the mode go through ONE exchange buffer one after the other -- half the LDS, twice the
+    // waves per CU, one more barrier per chain.  Pays for the ridge solve of the mid-size lines (measured at 480:
+    // 0.255 -> 0.220 ms; loses for the 640-point lines and for the product kernels, which stay two-buffer).
+#ifndef KCC_B_SEQ_SOLVE
+#define KCC_B_SEQ_SOLVE 1
+#endif
+    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T < 64;
+    static constexpr int NV = (!SEQ && (MODE == 2 || MODE == 3 || MODE == 4)) ? 2 : 1;
     static constexpr int LK = (T >= 128) ? (NV == 2 ? KCC_BLK_HUGE2 : KCC_BLK_HUGE) : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
                                                         : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
     static constexpr int NT = LK * T;
@@ -1277,7 +1345,17 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
 #pragma unroll
         for (int q = 0; q < DI::RF; ++q) pr[0][q] = make_float2(zv[q].x * zv[q].x + zv[q].y * zv[q].y, 0.f);
-        if (!nofft) fft_chain<P, true, 2>(pr, o, j, ex2, a.tw_i);
+        if (!nofft) {
+            if (C::SEQ) {
+                float2 (&p0)[1][DI::RF] = reinterpret_cast<float2 (&)[1][DI::RF]>(pr[0]); float2 (&p1)[1][DI::RF] = reinterpret_cast<float2 (&)[1][DI::RF]>(pr[1]);
+                float2 (&o0)[1][DI::RL] = reinterpret_cast<float2 (&)[1][DI::RL]>(o[0]);  float2 (&o1)[1][DI::RL] = reinterpret_cast<float2 (&)[1][DI::RL]>(o[1]);
+                fft_chain<P, true, 1>(p0, o0, j, ex1, a.tw_i);
+                __syncthreads();
+                fft_chain<P, true, 1>(p1, o1, j, ex1, a.tw_i);
+            } else {
+                fft_chain<P, true, 2>(pr, o, j, ex2, a.tw_i);
+            }
+        }
         if (vst && j < DI::ML) {
             float2* d = a.dst + (size_t)item * a.dst_stride + loff;
             if (a.zz_half > 0) {
@@ -1366,7 +1444,17 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         load_strided(vin[1], src + a.in_plane_stride, DF::MF, valid && j < DF::MF);
         const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 0]));
         const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
-        if (!nofft) fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
+        if (!nofft) {
+            if (C::SEQ) {
+                float2 (&v0)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[0]); float2 (&v1)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[1]);
+                float2 (&k0)[1][DF::RL] = reinterpret_cast<float2 (&)[1][DF::RL]>(kk[0]);  float2 (&k1)[1][DF::RL] = reinterpret_cast<float2 (&)[1][DF::RL]>(kk[1]);
+                fft_chain<P, false, 1>(v0, k0, j, ex1, a.tw_f);
+                __syncthreads();
+                fft_chain<P, false, 1>(v1, k1, j, ex1, a.tw_f);
+            } else {
+                fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
+            }
+        }
         // ML is even for every plan, so (-1)^l is the same for all q: one sign per thread
         static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
