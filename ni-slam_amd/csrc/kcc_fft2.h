@@ -84,10 +84,13 @@ struct Plan {
     template <bool INV> static constexpr int RF() { return INV ? (NP == 3 ? R3_ : R2_) : R1_; }   // first radix
     template <bool INV> static constexpr int RM() { return R2_; }                                  // middle (NP==3)
     template <bool INV> static constexpr int RL() { return INV ? R1_ : (NP == 3 ? R3_ : R2_); }   // last radix
-    // exchange buffer: index i is stored at i + i/PAD (PAD = first radix of the direction): pass-1 writes
-    // (stride RF) become stride RF+1 and the later strided-run writes land on distinct banks.
-    static constexpr int RMIN = (R3_ > 1 && R3_ < (R1_ < R2_ ? R1_ : R2_)) ? R3_ : (R1_ < R2_ ? R1_ : R2_);
-    static constexpr int EXT = N_ + N_ / RMIN + 2;
+    // exchange buffer: index i is stored at i + padc(RF) * (i / RF) (RF = first radix of the direction): the pass-1 writes of
+    // neighbouring threads (stride RF) become stride RF + padc, which is always ODD -- an even stride in float2 puts the 16
+    // lanes of a write group on 16 or fewer banks (an odd first radix with one pad element, e.g. the inverse 240 = 15 x 16
+    // plan, put all of them on ONE bank pair: 16-way conflicts in every inverse kernel of the 640x480 image family)
+    static constexpr int padc(int rf) { return (rf % 2 == 0) ? 1 : 2; }
+    static constexpr int ext_dir(int rf) { return N_ + padc(rf) * (N_ / rf); }
+    static constexpr int EXT = cmax(ext_dir(R1_), ext_dir(R3_ > 1 ? R3_ : R2_)) + 2;
 };
 
 // instantiated lengths
@@ -145,13 +148,13 @@ template <class P, bool INV> struct Dir {
     static constexpr int RF = P::template RF<INV>(), RM = P::template RM<INV>(), RL = P::template RL<INV>();
     static constexpr int MF = N / RF, ML = N / RL;           // butterflies (= active threads) in first / last pass
     static constexpr int MM = P::NP == 3 ? N / RM : 0;
-    static constexpr int PAD = RF;
+    static constexpr int PAD = RF, PADC = P::padc(RF);
     static constexpr int OFF3 = RM * RF;
-    // strided reads i = j + q*M map to phys(j) + q*(M + M/PAD) when PAD divides M (true for every plan here)
+    // strided reads i = j + q*M map to phys(j) + q*(M + PADC*M/PAD) when PAD divides M (true for every plan here)
     static_assert(ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0), "pad must divide the pass strides");
-    static constexpr int SL = ML + ML / PAD;                 // phys stride of last-pass reads
-    static constexpr int SM = P::NP == 3 ? MM + MM / PAD : 0;
-    __device__ static __forceinline__ unsigned phys(unsigned i) { return i + i / (unsigned)PAD; }
+    static constexpr int SL = ML + PADC * (ML / PAD);        // phys stride of last-pass reads
+    static constexpr int SM = P::NP == 3 ? MM + PADC * (MM / PAD) : 0;
+    __device__ static __forceinline__ unsigned phys(unsigned i) { return i + (unsigned)PADC * (i / (unsigned)PAD); }
 };
 
 // Run all passes of one direction on NV independent lines owned by this thread (same j, different data),
@@ -179,12 +182,12 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
     using D = Dir<P, INV>;
     constexpr int RF = D::RF, RL = D::RL, RM = D::RM;
     static_assert(RFV == RF && RLV == RL, "register arrays must match the plan's first / last radix");
-    // ---- pass 1: radix RF, Ns = 1 (no twiddles); output q of butterfly j goes to phys(j*RF + q) = j*(RF+1) + q
+    // ---- pass 1: radix RF, Ns = 1 (no twiddles); output q of butterfly j goes to phys(j*RF + q) = j*(RF+PADC) + q
     if (j < (unsigned)D::MF) {
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             dft_run<RF, INV>(vin[v]);
-            float2* w = ex[v] + j * (RF + 1);
+            float2* w = ex[v] + j * (RF + D::PADC);
 #pragma unroll
             for (int q = 0; q < RF; ++q) w[q] = vin[v][dft_pos<RF>(q)];
         }
@@ -210,15 +213,15 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
         }
         line_sync<WAVE>();
         if (act) {
-            // phys(jb*RF*RM + k + q*RF) = jb*(RF*RM + RM) + k + q*(RF+1)
-            const unsigned wb = jb * (RF * RM + RM) + k;
+            // phys(jb*RF*RM + k + q*RF) = jb*(RF*RM + PADC*RM) + k + q*(RF+PADC)
+            const unsigned wb = jb * (RF * RM + D::PADC * RM) + k;
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
 #pragma unroll
                 for (int q = 1; q < RM; ++q) vm[v][q] = cmul(vm[v][q], w2[q]);
                 dft_run<RM, INV>(vm[v]);
 #pragma unroll
-                for (int q = 0; q < RM; ++q) ex[v][wb + q * (RF + 1)] = vm[v][dft_pos<RM>(q)];
+                for (int q = 0; q < RM; ++q) ex[v][wb + q * (RF + D::PADC)] = vm[v][dft_pos<RM>(q)];
             }
         }
     }

@@ -20,6 +20,8 @@ if st: shutil.copy(st[0], out + "/%s_kernel_stats.csv" % tag)
 AF = {0: "plane", 1: "rot", 3: "u8", 4: "rot8", 5: "polar", 6: "polar", 7: "polar"}; AI = {0: "real", 1: "kernel_fwd", 2: "argmax", 3: "kernel_fwd", 4: "kernel_fwd", 5: "shifted"}
 BM = {0: "fwd", 1: "fwd_abs_inv", 2: "mul_inv", 3: "fwd_mul_inv", 4: "solve_inv", 5: "inv", 6: "zz_inv", 7: "mul_inv_x", 8: "fwd_mul_inv_x", 9: "solve_cached"}
 def stage(k):
+    mu = re.search(r"kA_fwd_u8<(\d+)>", k)
+    if mu: return "kA_fwd<%s,u8>" % mu.group(1)
     m = re.search(r"(kA_fwd|kA_inv|kB)<(\d+), (\d+)>", k)
     if not m:
         m2 = re.search(r"kcc::(k_\w+)\(", k); return m2.group(1) if m2 else None
