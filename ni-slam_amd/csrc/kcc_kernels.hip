@@ -921,7 +921,10 @@ __global__ __launch_bounds__((ICfg<HH, EPI>::NT), (ICfg<HH, EPI>::WPS)) void kA_
                 if (mirror) {
                     int y0 = (r ? H - r : 0) + H / 2; if (y0 >= H) y0 -= H;          // row -r
                     int y1 = (H - r - 1) + H / 2; if (y1 >= H) y1 -= H;              // row -(r + 1)
-                    colm[y0] = v0; colm[y1] = v1;
+                    // rows -(r+1), -r are neighbours in memory (except across the cyclic seam): one 8-byte store
+                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+                    if (y1 + 1 == y0) { f2u pr; pr.x = v1; pr.y = v0; *reinterpret_cast<f2u*>(colm + y1) = pr; }
+                    else { colm[y0] = v0; colm[y1] = v1; }
                 }
             }
         }
