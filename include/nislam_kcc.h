@@ -298,6 +298,11 @@ int  nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max
 void nik_pyramid_destroy(nik_pyramid* p);
 int  nik_pyramid_levels(const nik_pyramid* p, int* dims /* [levels][4]: H, W, PD, PC; may be NULL */);
 int  nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res);
+/* The same without the final wait: successive batches pipeline (the coarse levels of batch k+1 run beside the fine
+ * levels of batch k).  d_key, d_cur and res must stay valid, and res is not final, until nik_pyramid_synchronize or
+ * until two further batches have been enqueued. */
+int  nik_pyramid_track_dev_async(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res);
+int  nik_pyramid_synchronize(nik_pyramid* p);
 const char* nik_pyramid_last_error(const nik_pyramid* p, int level);
 
 /* ---- 2-D pose-graph optimisation (MapBuilder::OptimizeMap, map_builder.cc:195-271) ------------------------
@@ -353,6 +358,14 @@ int nik_pose_batch_chained(nik_ctx* ctx, int n, const nik_frame* keys, const nik
 int nik_wait_for(nik_ctx* ctx, nik_ctx* other);
 /* nik_downsample_u8_dev, asynchronous on nik_stream(ctx) */
 int nik_downsample_u8_async(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out);
+/* the same on a caller-owned hipStream_t of ctx's device (no ordering against ctx's own streams) */
+int nik_downsample_u8_stream(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out, void* stream);
+/* `stream` waits for everything ctx has enqueued so far / every stream of ctx waits for what `stream` holds so far */
+int nik_stream_wait_ctx(nik_ctx* ctx, void* stream);
+int nik_ctx_wait_stream(nik_ctx* ctx, void* stream);
+/* number of asynchronous calls (sync = 0) a stream of ctx keeps in flight before the next call blocks on the oldest:
+ * 1..4, default 2.  Drains the context. */
+int nik_set_call_depth(nik_ctx* ctx, int depth);
 
 /* ---- residual statistics of a batch, reduced on the device --------------------------------------
  * stats = [sum PSR_t (chosen hypothesis), sum PSR_r, sum |t|^2 (px^2), count] over the pairs of the latest

@@ -20,6 +20,7 @@ struct nik_pyramid {
     std::vector<nik_ctx*> ctx;                 // [level]
     std::vector<int> h, w, pd, pc;
     std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer)
+    hipStream_t ds = nullptr;                  // the box-filter chain runs beside the levels' own streams
 };
 
 extern "C" {
@@ -29,6 +30,7 @@ void nik_pyramid_destroy(nik_pyramid* p) {
     for (nik_ctx* c : p->ctx) if (c) nik_destroy(c);
     for (uint8_t* b : p->d_key) if (b) (void)hipFree(b);
     for (uint8_t* b : p->d_cur) if (b) (void)hipFree(b);
+    if (p->ds) (void)hipStreamDestroy(p->ds);
     delete p;
 }
 
@@ -46,13 +48,15 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
         c.rotation_divisor = cfg->rotation_divisor * num / den; c.rotation_channel = cfg->rotation_channel * num / den;
         c.height = H >> l; c.width = W >> l;
         p->h.push_back(H >> l); p->w.push_back(W >> l); p->pd.push_back(c.rotation_divisor); p->pc.push_back(c.rotation_channel);
-        const int rc = nik_create(&c, H >> l, W >> l, max_batch, 2 * max_batch, device, &p->ctx[l]);
+        int rc = nik_create(&c, H >> l, W >> l, max_batch, 2 * max_batch, device, &p->ctx[l]);
+        if (!rc) rc = nik_set_call_depth(p->ctx[l], 4);            // key spectra + current spectra + pose per batch, two batches in flight
         if (rc) { nik_pyramid_destroy(p); return rc; }
         if (l > 0) {
             const size_t bytes = (size_t)max_batch * (H >> l) * (W >> l);
             if (hipMalloc(&p->d_key[l], bytes) != hipSuccess || hipMalloc(&p->d_cur[l], bytes) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
         }
     }
+    if (hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
     *out = p;
     return NIK_OK;
 }
@@ -63,7 +67,7 @@ int nik_pyramid_levels(const nik_pyramid* p, int* dims /* [levels][4]: H, W, PD,
     return p->levels;
 }
 
-int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res) {
+int nik_pyramid_track_dev_async(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res) {
     if (!p || !d_key || !d_cur || !res || n < 0 || radius < 0) return NIK_ERR_INVALID_ARG;
     if (n == 0) return NIK_OK;
     if (n > p->max_batch) return NIK_ERR_CAPACITY;
@@ -71,13 +75,14 @@ int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uin
     int rc;
     std::vector<const uint8_t*> key(L), cur(L);
     key[0] = d_key; cur[0] = d_cur;
-    // every level's frames first: level l is the 2x2 box filter of level l - 1, produced on level l - 1's stream (its
-    // geometry), and level l's streams wait for it.  From here on nothing returns to the host until the finest level has
-    // been enqueued.
+    // every level's frames first: level l is the 2x2 box filter of level l - 1, produced on the pyramid's own stream
+    // (after level l has finished reading the previous batch's frames), and level l's streams wait for it.  Nothing
+    // returns to the host, and the box filters of batch k+1 do not queue behind the finest level of batch k.
     for (int l = 1; l < L; ++l) {
-        if ((rc = nik_downsample_u8_async(p->ctx[l - 1], n, key[l - 1], p->d_key[l])) ||
-            (rc = nik_downsample_u8_async(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l])) ||
-            (rc = nik_wait_for(p->ctx[l], p->ctx[l - 1]))) return rc;
+        if ((rc = nik_stream_wait_ctx(p->ctx[l], p->ds)) ||
+            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, key[l - 1], p->d_key[l], p->ds)) ||
+            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l], p->ds)) ||
+            (rc = nik_ctx_wait_stream(p->ctx[l], p->ds))) return rc;
         key[l] = p->d_key[l]; cur[l] = p->d_cur[l];
     }
     std::vector<nik_frame> ks(n), cs(n);
@@ -95,8 +100,19 @@ int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uin
                 (rc = nik_pose_batch_chained(c, n, ks.data(), cs.data(), p->ctx[l + 1], radius, out, 0))) return rc;
         }
     }
-    for (int l = 0; l < L; ++l) if ((rc = nik_synchronize(p->ctx[l]))) return rc;
     return NIK_OK;
+}
+
+int nik_pyramid_synchronize(nik_pyramid* p) {
+    if (!p) return NIK_ERR_INVALID_ARG;
+    int rc;
+    for (int l = 0; l < p->levels; ++l) if ((rc = nik_synchronize(p->ctx[l]))) return rc;
+    return NIK_OK;
+}
+
+int nik_pyramid_track_dev(nik_pyramid* p, int n, const uint8_t* d_key, const uint8_t* d_cur, int radius, nik_pose_result* res) {
+    int rc = nik_pyramid_track_dev_async(p, n, d_key, d_cur, radius, res);
+    return rc ? rc : nik_pyramid_synchronize(p);
 }
 
 const char* nik_pyramid_last_error(const nik_pyramid* p, int level) {

@@ -28,7 +28,8 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
-           "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_last_error", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
+           "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
+           "nik_downsample_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
            "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
@@ -160,6 +161,12 @@ def load():
         L.nik_pyramid_destroy.restype = None
         L.nik_pyramid_levels.argtypes = [P, P]
         L.nik_pyramid_track_dev.argtypes = [P, I, P, P, I, P]
+        L.nik_pyramid_track_dev_async.argtypes = [P, I, P, P, I, P]
+        L.nik_pyramid_synchronize.argtypes = [P]
+        L.nik_downsample_u8_stream.argtypes = [P, I, P, P, P]
+        L.nik_stream_wait_ctx.argtypes = [P, P]
+        L.nik_ctx_wait_stream.argtypes = [P, P]
+        L.nik_set_call_depth.argtypes = [P, I]
         L.nik_pyramid_last_error.argtypes = [P, I]
         L.nik_pyramid_last_error.restype = C.c_char_p
         L.nik_map_create.argtypes = [P, P, P]
@@ -796,6 +803,28 @@ class Pyramid:
                                            C.cast(res, C.c_void_p))
         if rc:
             raise NikError(rc, "; ".join(self._L.nik_pyramid_last_error(self._p, l).decode() for l in range(self.levels)))
+        return [[res[l * n + i].as_dict() for i in range(n)] for l in range(self.levels)]
+
+    def _raise(self, rc):
+        raise NikError(rc, "; ".join(self._L.nik_pyramid_last_error(self._p, l).decode() for l in range(self.levels)))
+
+    def track_dev_async(self, d_key_ptr, d_cur_ptr, n, radius=4, res=None):
+        """enqueue one batch without waiting; `res` (NikPoseResult * (levels * n)) is final after synchronize().  Successive
+        batches pipeline: the frames and `res` of a batch must stay alive until then."""
+        if res is None:
+            res = (NikPoseResult * (self.levels * n))()
+        rc = self._L.nik_pyramid_track_dev_async(self._p, int(n), C.c_void_p(int(d_key_ptr)), C.c_void_p(int(d_cur_ptr)), int(radius),
+                                                 C.cast(res, C.c_void_p))
+        if rc:
+            self._raise(rc)
+        return res
+
+    def synchronize(self):
+        rc = self._L.nik_pyramid_synchronize(self._p)
+        if rc:
+            self._raise(rc)
+
+    def as_lists(self, res, n):
         return [[res[l * n + i].as_dict() for i in range(n)] for l in range(self.levels)]
 
 
