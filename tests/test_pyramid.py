@@ -99,3 +99,30 @@ def test_pyramid_matches_oracle_and_plain_kcc():
     for i in range(n):
         assert again[i].as_dict()["pose"] == plain[i].as_dict()["pose"]
     pyr.close()
+
+
+@pytest.mark.gpu
+def test_pyramid_batches_in_flight_equal_single_batches():
+    """nik_pyramid_track_dev_async: several DIFFERENT batches enqueued back to back (the levels of consecutive batches
+    overlap, frame slots and box-filter buffers are recycled under stream order) give, after one synchronize, exactly
+    what each batch gives alone."""
+    import torch
+    N = nik()
+    H, W, levels, radius, n, nb = FULL["H"], FULL["W"], 4, 4, 6, 5
+    pyr = N.Pyramid(N.default_config(), H, W, levels=levels, max_batch=n)
+    batches = []
+    for b in range(nb):
+        keys, curs, _ = synth.make_unique_batch(n, H, W, seed0=700 + 31 * b, max_theta=6.0, max_shift=30)
+        batches.append((torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()))
+    torch.cuda.synchronize()
+    alone = [pyr.track_dev(dk.data_ptr(), dc.data_ptr(), n, radius) for dk, dc in batches]
+    raws = [pyr.track_dev_async(dk.data_ptr(), dc.data_ptr(), n, radius) for dk, dc in batches]
+    pyr.synchronize()
+    for b in range(nb):
+        got = pyr.as_lists(raws[b], n)
+        for l in range(levels):
+            for i in range(n):
+                assert got[l][i] == alone[b][l][i], (b, l, i)
+    # distinct batches did give distinct answers (the comparison above is not vacuous)
+    assert len({tuple(alone[b][0][0]["pose"]) for b in range(nb)}) > 1
+    pyr.close()
