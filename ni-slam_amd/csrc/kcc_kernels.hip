@@ -904,27 +904,31 @@ __global__ __launch_bounds__((ICfg<HH, EPI>::NT), (ICfg<HH, EPI>::WPS)) void kA_
         const int xcol = x0 + line;
         const bool half = a.zz_tiles > 0;                    // columns > W/2 come from their mirrors
         if (j < DI::ML && !(half && xcol > a.cols / 2)) {
-            const int H = a.rows, W = a.cols, SP = H + 2;
+            // H is the template's: with 0 <= j < ML known, the cyclic wraps below fold to constants for all but the one or
+            // two q whose rows straddle H/2 (this epilogue was 60 % integer work with a run-time H)
+            constexpr int H = 2 * HH, SP = H + 2, HQ = H / 2;
+            __builtin_assume(j >= 0); __builtin_assume(j < DI::ML);
+            const int W = a.cols;
             int xs = xcol + W / 2; if (xs >= W) xs -= W;
             float* col = a.real_out + (size_t)item * a.real_stride + (size_t)xs * SP;
             // p(r, c) = p(-r, -c): the same values are column W - c read backwards
             const bool mirror = half && xcol != 0 && 2 * xcol != W;
             int xm = W - xcol + W / 2; if (xm >= W) xm -= W;
             float* colm = a.real_out + (size_t)item * a.real_stride + (size_t)xm * SP;
+            typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
 #pragma unroll
             for (int q = 0; q < DI::RL; ++q) {
-                const int r = 2 * (j + q * DI::ML);
-                int ys = r + H / 2; if (ys >= H) ys -= H;
+                const int r = 2 * j + 2 * q * DI::ML;
+                const int ys = r >= HQ ? r - HQ : r + HQ;
                 const float v0 = vout[0][q].x * rsize, v1 = vout[0][q].y * rsize;
-                if ((H / 2) & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
+                if (HQ & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
                 else *reinterpret_cast<float2*>(col + ys) = make_float2(v0, v1);
                 if (mirror) {
-                    int y0 = (r ? H - r : 0) + H / 2; if (y0 >= H) y0 -= H;          // row -r
-                    int y1 = (H - r - 1) + H / 2; if (y1 >= H) y1 -= H;              // row -(r + 1)
-                    // rows -(r+1), -r are neighbours in memory (except across the cyclic seam): one 8-byte store
-                    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-                    if (y1 + 1 == y0) { f2u pr; pr.x = v1; pr.y = v0; *reinterpret_cast<f2u*>(colm + y1) = pr; }
-                    else { colm[y0] = v0; colm[y1] = v1; }
+                    // rows -r and -(r+1) sit at y0 = (HQ - r) mod H and y0 - 1: neighbours in memory except across the
+                    // cyclic seam (r == HQ), so one 8-byte store
+                    const int y0 = r > HQ ? 3 * HQ - r : HQ - r;
+                    if (r == HQ) { colm[0] = v0; colm[H - 1] = v1; }
+                    else { f2u pr; pr.x = v1; pr.y = v0; *reinterpret_cast<f2u*>(colm + y0 - 1) = pr; }
                 }
             }
         }
