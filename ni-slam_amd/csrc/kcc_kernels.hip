@@ -410,7 +410,18 @@ template <int HH> using FCfg = ACfg<HH, (HH >= 360 ? KCC_FLX360 : KCC_ALX), fals
 __host__ __device__ constexpr int inv_lx(int hh, int epi) {
     return (epi == EPI_ARGMAX || epi == EPI_ARGMAX_WIN) ? (hh >= 360 ? KCC_ALX_AM360 : KCC_ALX_AM) : a_lx(hh);
 }
-template <int HH, int EPI> using ICfg = ACfg<HH, inv_lx(HH, EPI), true>;
+// Preferred lines per workgroup of the inverse kernels where it divides the plane's columns (run-time choice, LXO template
+// argument): 12 lines of the 360-point family = 240 threads = 3.75 waves and 96-byte row segments, against 8 lines = 160
+// threads = 2.5 waves (a half-empty third wave) and 64-byte segments (kernel_fwd at 720x480: 0.314 -> 0.291 ms)
+#ifndef KCC_ALXP360
+#define KCC_ALXP360 12
+#endif
+#ifndef KCC_ALXP240
+#define KCC_ALXP240 0
+#endif
+__host__ __device__ constexpr int pref_lx(int hh) { return hh == 360 ? KCC_ALXP360 : (hh == 240 ? KCC_ALXP240 : 0); }
+inline int inv_lx_for(int hh, int cols, int epi) { const int p = pref_lx(hh); return (p > 0 && cols % p == 0) ? p : inv_lx(hh, epi); }
+template <int HH, int EPI, int LXO = 0> using ICfg = ACfg<HH, (LXO > 0 ? LXO : inv_lx(HH, EPI)), true>;
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
@@ -847,10 +858,10 @@ __device__ __forceinline__ bool win_hit(int r, int centre, int rows, int radius,
     return d <= radius;
 }
 
-template <int HH, int EPI>
-__global__ __launch_bounds__((ICfg<HH, EPI>::NT), (ICfg<HH, EPI>::WPS)) void kA_inv(AArgs a) {
+template <int HH, int EPI, int LXO = 0>
+__global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)) void kA_inv(AArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    using C = ICfg<HH, EPI>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
+    using C = ICfg<HH, EPI, LXO>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
     constexpr int NW = (C::NT + 63) / 64;
     float2* lds = reinterpret_cast<float2*>(smem);
@@ -1040,11 +1051,11 @@ Rot8Geom rot8_geom(int hh) {
     return r;
 }
 // columns [0, W/2] rounded up to whole kernel_fwd tiles: what the Hermitian-half Kzz transform reads of the zz plane
-int zz_half_columns(PlaneGeom g) { const int lx = a_lx(g.rows / 2); return std::min(g.cols, ((g.cols / 2) / lx + 1) * lx); }
+int zz_half_columns(PlaneGeom g) { const int lx = inv_lx_for(g.rows / 2, g.cols, EPI_KFWD_POLY3); return std::min(g.cols, ((g.cols / 2) / lx + 1) * lx); }
 // columns [0, min(W/2, need)] rounded up to whole tiles: what the even-half inverse row pass of the zero-phase image reads
 // when only its columns |c| <= need are consumed (the polar gather never leaves the inscribed circle)
-int shifted_columns(PlaneGeom g, int need) { const int lx = a_lx(g.rows / 2); return std::min(g.cols, (std::min(g.cols / 2, need) / lx + 1) * lx); }
-int argmax_blocks(PlaneGeom g) { return g.cols / inv_lx(g.rows / 2, EPI_ARGMAX); }
+int shifted_columns(PlaneGeom g, int need) { const int lx = inv_lx_for(g.rows / 2, g.cols, EPI_SHIFTED); return std::min(g.cols, (std::min(g.cols / 2, need) / lx + 1) * lx); }
+int argmax_blocks(PlaneGeom g) { return g.cols / inv_lx_for(g.rows / 2, g.cols, EPI_ARGMAX); }
 
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a, size_t min_lds = 0) {
     a.n_items = n_items;
@@ -1056,17 +1067,20 @@ template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items,
         lds_cap = bytes;
     hipLaunchKernelGGL((kA_fwd<HH, SRC>), grid, block, bytes, s, a);
 }
-template <int HH, int EPI> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
+template <int HH, int EPI, int LXO = 0> static void launchA_inv_t(hipStream_t s, int n_items, int nz, AArgs a) {
+    if constexpr (LXO == 0 && pref_lx(HH) > 0) {
+        if (a.cols % pref_lx(HH) == 0) { launchA_inv_t<HH, EPI, pref_lx(HH)>(s, n_items, nz, a); return; }
+    }
     a.n_items = n_items; a.tw_f = a.twI_f; a.tw_i = a.twI_i;       // tables of the inverse-kernel plan
-    using C = ICfg<HH, EPI>;
+    using C = ICfg<HH, EPI, LXO>;
     const int nbx = a.cols / C::LX;
     // zz_tiles (flag -> tile count): columns [0, min(W/2, zz_tiles - 1)] rounded up to whole tiles
     if (a.zz_tiles > 0) a.zz_tiles = std::min(a.cols / 2, a.zz_tiles - 1) / C::LX + 1;
     dim3 grid(a.zz_tiles > 0 ? (a.zz_tiles + (epi_is_kfwd(EPI) ? nbx : 0)) * n_items : nbx * n_items * nz), block(C::NT);
     static const bool big_lds = (C::BYTES > 65536) &&
-        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
+        (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI, LXO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
     (void)big_lds;
-    hipLaunchKernelGGL((kA_inv<HH, EPI>), grid, block, C::BYTES, s, a);
+    hipLaunchKernelGGL((kA_inv<HH, EPI, LXO>), grid, block, C::BYTES, s, a);
 }
 
 // polar forward kernel for `qs` first-pass points per thread and segment (one of the sizes fwd_geom() offers)
