@@ -90,7 +90,8 @@ struct Plan {
     // plan, put all of them on ONE bank pair: 16-way conflicts in every inverse kernel of the 640x480 image family)
     static constexpr int padc(int rf) { return (rf % 2 == 0) ? 1 : 2; }
     static constexpr int ext_dir(int rf) { return N_ + padc(rf) * (N_ / rf); }
-    static constexpr int EXT = cmax(ext_dir(R1_), ext_dir(R3_ > 1 ? R3_ : R2_)) + 2;
+    // (ext_dir is exact to within one element: the largest physical index is N - 1 + padc * ((N - 1) / rf) < ext_dir(rf))
+    static constexpr int EXT = cmax(ext_dir(R1_), ext_dir(R3_ > 1 ? R3_ : R2_));
 };
 
 // instantiated lengths

@@ -1080,6 +1080,11 @@ template <int HH, int EPI, int LXO = 0> static void launchA_inv_t(hipStream_t s,
     static const bool big_lds = (C::BYTES > 65536) &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI, LXO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
     (void)big_lds;
+#ifdef KCC_ABLATE
+    static const size_t lds_pad = getenv("NIK_LDS_PAD_A") ? (size_t)atoi(getenv("NIK_LDS_PAD_A")) : 0;   // occupancy experiments
+    hipLaunchKernelGGL((kA_inv<HH, EPI, LXO>), grid, block, std::min<size_t>(C::BYTES + lds_pad, 65536), s, a);
+    return;
+#endif
     hipLaunchKernelGGL((kA_inv<HH, EPI, LXO>), grid, block, C::BYTES, s, a);
 }
 
@@ -1501,6 +1506,11 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
     static const bool big_lds = (BYTES > 65536) &&
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES) == hipSuccess);
     (void)big_lds;
+#ifdef KCC_ABLATE
+    static const size_t lds_pad = getenv("NIK_LDS_PAD_B") ? (size_t)atoi(getenv("NIK_LDS_PAD_B")) : 0;   // occupancy experiments
+    hipLaunchKernelGGL((kB<N, MODE>), grid, block, std::min<size_t>(BYTES + lds_pad, 65536), s, a);
+    return;
+#endif
     hipLaunchKernelGGL((kB<N, MODE>), grid, block, BYTES, s, a);
 }
 
