@@ -1278,7 +1278,10 @@ template <int N, int MODE> struct BCfg {
 #ifndef KCC_B_SEQ_SOLVE
 #define KCC_B_SEQ_SOLVE 1
 #endif
-    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T < 64;
+#ifndef KCC_B_SEQ_TMAX
+#define KCC_B_SEQ_TMAX 64
+#endif
+    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T < KCC_B_SEQ_TMAX;
     static constexpr int NV = (!SEQ && (MODE == 2 || MODE == 3 || MODE == 4)) ? 2 : 1;
     static constexpr int LK = (T >= 128) ? (NV == 2 ? KCC_BLK_HUGE2 : KCC_BLK_HUGE) : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
                                                         : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
