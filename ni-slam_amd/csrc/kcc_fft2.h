@@ -73,6 +73,9 @@ __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
 
 __host__ __device__ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+#ifndef KCC_SWZ16
+#define KCC_SWZ16 1
+#endif
 // FFT plan: N = R1*R2 (*R3).  Forward applies R1, R2, R3; inverse applies them reversed.
 template <int N_, int R1_, int R2_, int R3_ = 1>
 struct Plan {
@@ -88,7 +91,12 @@ struct Plan {
     // neighbouring threads (stride RF) become stride RF + padc, which is always ODD -- an even stride in float2 puts the 16
     // lanes of a write group on 16 or fewer banks (an odd first radix with one pad element, e.g. the inverse 240 = 15 x 16
     // plan, put all of them on ONE bank pair: 16-way conflicts in every inverse kernel of the 640x480 image family)
-    static constexpr int padc(int rf) { return (rf % 2 == 0) ? 1 : 2; }
+    // SWZ plans (240 = 16 x 15): no padding at all.  The radix-16 direction stores index i at i ^ ((i >> 4) & 15) -- its
+    // pass-1 writes (stride 16) and last-pass reads (16 consecutive) both touch 16 different bank pairs -- and the radix-15
+    // direction needs none (an odd stride already does).  The buffer shrinks from 272 to 240 elements per line, below the
+    // natural-order pitch, and the 240-point A kernels fit FIVE workgroups per CU instead of four (32 KB each was the limit).
+    static constexpr bool SWZ = KCC_SWZ16 && R3_ == 1 && ((R1_ == 16 && N_ / R2_ == 16) || (R2_ == 16 && N_ / R1_ == 16)) && ((R1_ == 16 ? R2_ : R1_) % 2 == 1);
+    static constexpr int padc(int rf) { return SWZ ? 0 : ((rf % 2 == 0) ? 1 : 2); }
     static constexpr int ext_dir(int rf) { return N_ + padc(rf) * (N_ / rf); }
     // (ext_dir is exact to within one element: the largest physical index is N - 1 + padc * ((N - 1) / rf) < ext_dir(rf))
     static constexpr int EXT = cmax(ext_dir(R1_), ext_dir(R3_ > 1 ? R3_ : R2_));
@@ -150,6 +158,7 @@ template <class P, bool INV> struct Dir {
     static constexpr int MF = N / RF, ML = N / RL;           // butterflies (= active threads) in first / last pass
     static constexpr int MM = P::NP == 3 ? N / RM : 0;
     static constexpr int PAD = RF, PADC = P::padc(RF);
+    static constexpr bool SWZ = P::SWZ && RF == 16;          // XOR-swizzled exchange (see Plan::SWZ)
     static constexpr int OFF3 = RM * RF;
     // strided reads i = j + q*M map to phys(j) + q*(M + PADC*M/PAD) when PAD divides M (true for every plan here)
     static_assert(ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0), "pad must divide the pass strides");
@@ -188,9 +197,16 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             dft_run<RF, INV>(vin[v]);
-            float2* w = ex[v] + j * (RF + D::PADC);
+            if constexpr (D::SWZ) {
+                float2* w = ex[v] + j * 16;
+                const unsigned t = j & 15u;
 #pragma unroll
-            for (int q = 0; q < RF; ++q) w[q] = vin[v][dft_pos<RF>(q)];
+                for (int q = 0; q < RF; ++q) w[t ^ (unsigned)q] = vin[v][dft_pos<RF>(q)];
+            } else {
+                float2* w = ex[v] + j * (RF + D::PADC);
+#pragma unroll
+                for (int q = 0; q < RF; ++q) w[q] = vin[v][dft_pos<RF>(q)];
+            }
         }
     }
     if constexpr (P::NP == 3) {
@@ -240,8 +256,14 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             float2 t[RL];
+            if constexpr (D::SWZ) {
+                static_assert(D::ML == 16 && P::NP == 2, "swizzle assumes 16 last-pass butterflies");
 #pragma unroll
-            for (int q = 0; q < RL; ++q) t[q] = ex[v][pj + q * D::SL];
+                for (int q = 0; q < RL; ++q) t[q] = ex[v][16 * q + (j ^ (unsigned)(q & 15))];
+            } else {
+#pragma unroll
+                for (int q = 0; q < RL; ++q) t[q] = ex[v][pj + q * D::SL];
+            }
 #pragma unroll
             for (int q = 1; q < RL; ++q) t[q] = cmul(t[q], wl[q]);
             dft_run<RL, INV>(t);

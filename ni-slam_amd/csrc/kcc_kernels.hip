@@ -781,7 +781,8 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #define KCC_U8_TPW 2
 #endif
 template <int HH>
-__global__ __launch_bounds__(FCfg<HH>::NT, FCfg<HH>::WPS) void kA_fwd_u8(AArgs a, int tpw) {
+// (the register prefetch of the next tile needs ~123 VGPRs: never ask for more than 4 waves per SIMD)
+__global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > 4 ? 4 : FCfg<HH>::WPS)) void kA_fwd_u8(AArgs a, int tpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
