@@ -96,7 +96,12 @@ struct Plan {
     // direction needs none (an odd stride already does).  The buffer shrinks from 272 to 240 elements per line, below the
     // natural-order pitch, and the 240-point A kernels fit FIVE workgroups per CU instead of four (32 KB each was the limit).
     static constexpr bool SWZ = KCC_SWZ16 && R3_ == 1 && ((R1_ == 16 && N_ / R2_ == 16) || (R2_ == 16 && N_ / R1_ == 16)) && ((R1_ == 16 ? R2_ : R1_) % 2 == 1);
-    static constexpr int padc(int rf) { return SWZ ? 0 : ((rf % 2 == 0) ? 1 : 2); }
+    // SWZ3 (640 = 8 x 8 x 10): likewise no padding.  Forward: exchange 1 stores i at i ^ ((i >> 5) & 3), exchange 2 at
+    // i ^ (((i >> 6) & 1) << 3); inverse (first radix 10: stride 10 is conflict-free as it is): plain.  Every write and read of
+    // both directions is conflict-free (tools/lds_sim3.py), and the line shrinks from 720 to 640 elements: the two-plane
+    // 640-point B kernels fit five workgroups per CU instead of four.
+    static constexpr bool SWZ3 = KCC_SWZ16 && N_ == 640 && R1_ == 8 && R2_ == 8 && R3_ == 10;
+    static constexpr int padc(int rf) { return (SWZ || SWZ3) ? 0 : ((rf % 2 == 0) ? 1 : 2); }
     static constexpr int ext_dir(int rf) { return N_ + padc(rf) * (N_ / rf); }
     // (ext_dir is exact to within one element: the largest physical index is N - 1 + padc * ((N - 1) / rf) < ext_dir(rf))
     static constexpr int EXT = cmax(ext_dir(R1_), ext_dir(R3_ > 1 ? R3_ : R2_));
@@ -159,6 +164,7 @@ template <class P, bool INV> struct Dir {
     static constexpr int MM = P::NP == 3 ? N / RM : 0;
     static constexpr int PAD = RF, PADC = P::padc(RF);
     static constexpr bool SWZ = P::SWZ && RF == 16;          // XOR-swizzled exchange (see Plan::SWZ)
+    static constexpr bool S3F = P::SWZ3 && !INV;             // XOR-swizzled exchanges of the 3-pass forward direction
     static constexpr int OFF3 = RM * RF;
     // strided reads i = j + q*M map to phys(j) + q*(M + PADC*M/PAD) when PAD divides M (true for every plan here)
     static_assert(ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0), "pad must divide the pass strides");
@@ -202,6 +208,12 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
                 const unsigned t = j & 15u;
 #pragma unroll
                 for (int q = 0; q < RF; ++q) w[t ^ (unsigned)q] = vin[v][dft_pos<RF>(q)];
+            } else if constexpr (D::S3F) {
+                static_assert(RF == 8 && RM == 8 && D::MM == 80 && D::ML == 64, "swizzle constants are the 8 x 8 x 10 plan's");
+                float2* w = ex[v] + j * 8;
+                const unsigned t = (j >> 2) & 3u;                // (i >> 5) & 3 for i = 8 j + q
+#pragma unroll
+                for (int q = 0; q < RF; ++q) w[t ^ (unsigned)q] = vin[v][dft_pos<RF>(q)];
             } else {
                 float2* w = ex[v] + j * (RF + D::PADC);
 #pragma unroll
@@ -223,10 +235,20 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
         line_sync<WAVE>();
         if (act) {
             const unsigned pj = D::phys(j);
+            if constexpr (D::S3F) {
+                unsigned ri[RM];
 #pragma unroll
-            for (int v = 0; v < NV; ++v)
+                for (int q = 0; q < RM; ++q) { const unsigned i = j + (unsigned)(q * MM); ri[q] = i ^ ((i >> 5) & 3u); }
 #pragma unroll
-                for (int q = 0; q < RM; ++q) vm[v][q] = ex[v][pj + q * D::SM];
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int q = 0; q < RM; ++q) vm[v][q] = ex[v][ri[q]];
+            } else {
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int q = 0; q < RM; ++q) vm[v][q] = ex[v][pj + q * D::SM];
+            }
         }
         line_sync<WAVE>();
         if (act) {
@@ -237,8 +259,14 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
 #pragma unroll
                 for (int q = 1; q < RM; ++q) vm[v][q] = cmul(vm[v][q], w2[q]);
                 dft_run<RM, INV>(vm[v]);
+                if constexpr (D::S3F) {
+                    const unsigned t2 = (jb & 1u) << 3;          // ((i >> 6) & 1) << 3 for i = 64 jb + k + 8 q
 #pragma unroll
-                for (int q = 0; q < RM; ++q) ex[v][wb + q * (RF + D::PADC)] = vm[v][dft_pos<RM>(q)];
+                    for (int q = 0; q < RM; ++q) ex[v][wb + ((unsigned)(q * RF) ^ t2)] = vm[v][dft_pos<RM>(q)];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < RM; ++q) ex[v][wb + q * (RF + D::PADC)] = vm[v][dft_pos<RM>(q)];
+                }
             }
         }
     }
@@ -260,6 +288,10 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
                 static_assert(D::ML == 16 && P::NP == 2, "swizzle assumes 16 last-pass butterflies");
 #pragma unroll
                 for (int q = 0; q < RL; ++q) t[q] = ex[v][16 * q + (j ^ (unsigned)(q & 15))];
+            } else if constexpr (D::S3F) {
+                const unsigned j8 = j ^ 8u;                      // i ^ (((i >> 6) & 1) << 3) for i = j + 64 q
+#pragma unroll
+                for (int q = 0; q < RL; ++q) t[q] = ex[v][((q & 1) ? j8 : j) + q * 64];
             } else {
 #pragma unroll
                 for (int q = 0; q < RL; ++q) t[q] = ex[v][pj + q * D::SL];
