@@ -165,3 +165,44 @@ def test_rot8_boxes_hold_for_every_angle(H, W):
         assert (xhi - (xlo & ~3) < PITCH).all() and (yhi - ylo < BH).all(), deg2
         # single-step BORDER_WRAP while staging: every staged coordinate within one period of the image
         assert ((xlo & ~3) >= -W).all() and ((xlo & ~3) + PITCH <= 2 * W).all() and (ylo >= -H).all() and (ylo + BH <= 2 * H).all(), deg2
+
+
+def test_exchange_swizzles_are_conflict_free_permutations():
+    """kcc_fft2.h stores the unpadded exchange buffers of the 240- and 640-point plans at XOR-swizzled positions.  Each
+    swizzle must be a permutation of [0, N) (nothing is overwritten) and, per tools/lds_sim3.py's bank model (64 dword banks,
+    16-lane b64 writes, 32-lane b64 reads), every access of the plan must be conflict-free at the shipped workgroup shapes."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    from lds_sim3 import worst, epitch
+    assert sorted(i ^ ((i >> 4) & 15) for i in range(240)) == list(range(240))
+    assert sorted(i ^ ((i >> 5) & 3) for i in range(640)) == list(range(640))
+    assert sorted(i ^ (((i >> 6) & 1) << 3) for i in range(640)) == list(range(640))
+    # 640 = 8 x 8 x 10, T = 80 threads per line, 3 (two-plane kernels) or 4 lines per workgroup
+    T, EP = 80, epitch(640, 80)
+    assert EP == 656
+    for lines in (3, 4):
+        NT = lines * T
+        acc = {
+            "f w1": [(lambda lk, j, q=q: lk * EP + 8 * j + (q ^ ((j >> 2) & 3)), 80, 16) for q in range(8)],
+            "f r2": [(lambda lk, j, q=q: lk * EP + ((j + 80 * q) ^ (((j + 80 * q) >> 5) & 3)), 80, 32) for q in range(8)],
+            "f w2": [(lambda lk, j, q=q: lk * EP + ((64 * (j // 8) + j % 8 + 8 * q) ^ (((j // 8) & 1) << 3)), 80, 16) for q in range(8)],
+            "f r3": [(lambda lk, j, q=q: lk * EP + ((j + 64 * q) ^ (8 * (q & 1))), 64, 32) for q in range(10)],
+            "i w1": [(lambda lk, j, q=q: lk * EP + 10 * j + q, 64, 16) for q in range(10)],
+            "i r2": [(lambda lk, j, q=q: lk * EP + j + 80 * q, 80, 32) for q in range(8)],
+            "i w2": [(lambda lk, j, q=q: lk * EP + 80 * (j // 10) + j % 10 + 10 * q, 80, 16) for q in range(8)],
+            "i r3": [(lambda lk, j, q=q: lk * EP + j + 80 * q, 80, 32) for q in range(8)],
+        }
+        for name, lst in acc.items():
+            for f, active, group in lst:
+                assert worst(f, lambda j, a=active: j < a, NT, T, group) == 1, (lines, name)
+    # 240 = 16 x 15, T = 16, 16 lines per workgroup, line pitch 240
+    T, EP, NT = 16, epitch(240, 16), 256
+    assert EP == 240
+    for q in range(16):
+        assert worst(lambda lk, j, q=q: lk * EP + 16 * j + (q ^ (j & 15)), lambda j: j < 15, NT, T, 16) == 1
+    for q in range(15):
+        assert worst(lambda lk, j, q=q: lk * EP + 16 * q + (j ^ (q & 15)), lambda j: j < 16, NT, T, 32) == 1
+    for q in range(15):                                       # inverse: first radix 15, plain
+        assert worst(lambda lk, j, q=q: lk * EP + 15 * j + q, lambda j: j < 16, NT, T, 16) == 1
+    for q in range(16):
+        assert worst(lambda lk, j, q=q: lk * EP + j + 15 * q, lambda j: j < 15, NT, T, 32) <= 2
