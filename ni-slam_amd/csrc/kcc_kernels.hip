@@ -349,6 +349,10 @@ struct AArgs {
     KernelFn fn; unsigned* maxbuf; const float* energy;
 };
 
+// most waves per SIMD ever asked of the register allocator: the 360-point kernels need ~100 VGPRs (a 96-register cap spilled)
+#ifndef KCC_WPS_MAX
+#define KCC_WPS_MAX(hh) ((hh) >= 360 ? 4 : 8)
+#endif
 template <int HH, int LXV, bool INVPLAN> struct ACfg {
     static constexpr int HALF = HH;
     using P = typename std::conditional<INVPLAN, PlanInv<HH>, PlanFor<HH>>::type;
@@ -363,7 +367,7 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
     // waves per SIMD the LDS footprint allows: ask the register allocator to fit that occupancy
     static constexpr int BLOCKS = (int)(160 * 1024 / BYTES) > 8 ? 8 : (int)(160 * 1024 / BYTES);
     static constexpr int WPS_ = (BLOCKS * ((NT + 63) / 64) + 3) / 4;
-    static constexpr int WPS = WPS_ > 8 ? 8 : (WPS_ < 1 ? 1 : WPS_);
+    static constexpr int WPS = WPS_ > KCC_WPS_MAX(HH) ? KCC_WPS_MAX(HH) : (WPS_ < 1 ? 1 : WPS_);
 };
 
 template <int RR>
@@ -781,8 +785,12 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #define KCC_U8_TPW 2
 #endif
 template <int HH>
-// (the register prefetch of the next tile needs ~123 VGPRs: never ask for more than 4 waves per SIMD)
-__global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > 4 ? 4 : FCfg<HH>::WPS)) void kA_fwd_u8(AArgs a, int tpw) {
+// (the register prefetch of the next tile needs ~123 VGPRs at 240 points and ~150 at 360: never ask for more waves per
+// SIMD than that leaves room for -- a 128-register cap made the 360-point kernel spill 33 dwords: 0.396 -> 0.331 ms at HD)
+#ifndef KCC_U8_WPS
+#define KCC_U8_WPS(hh) ((hh) >= 360 ? 3 : 4)
+#endif
+__global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC_U8_WPS(HH) : FCfg<HH>::WPS)) void kA_fwd_u8(AArgs a, int tpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
