@@ -484,3 +484,31 @@ def test_graph_replay_gives_identical_results(geom):
                 cf.set_graphs(0)
                 assert got == cf.pose_batch(ks2, cs2, small_rot)
     cf.close()
+
+
+def test_ragged_and_empty_batches_equal_single_pairs():
+    """Batch sizes around the stream-split thresholds (a call of >= 64 items is split over two streams, tails are ragged)
+    and the empty batch: every pair of every batch gives exactly what the pair gives alone."""
+    import torch
+    geom = SMALL
+    H, W = geom["H"], geom["W"]
+    nmax = 131
+    cf, _, _ = _mk(geom, max_batch=nmax, max_frames=2 * nmax)
+    keys, curs, _ = synth.make_unique_batch(nmax, H, W, seed0=4242, max_theta=8.0, max_shift=6, base_shift=8)
+    dk = torch.from_numpy(keys).cuda(); dc = torch.from_numpy(curs).cuda(); torch.cuda.synchronize()
+    cf.intermedium_batch_dev(dk.data_ptr(), nmax, list(range(nmax)))
+    ref = cf.track_batch_dev(dc.data_ptr(), list(range(nmax)), list(range(nmax, 2 * nmax)), True, sync=True)
+    alone = []
+    for i in (0, 31, 32, 63, 64, 65, 130):
+        r = cf.track_batch_dev(dc[i:i + 1].data_ptr(), [i], [nmax + i], True, sync=True)
+        alone.append((i, r[0].as_dict()))
+    for i, r in alone:
+        assert ref[i].as_dict() == r, i
+    for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 129, 130):
+        got = cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(nmax, nmax + n)), True, sync=True)
+        assert len(got) == n
+        for i in range(n):
+            assert got[i].as_dict() == ref[i].as_dict(), (n, i)
+        got2 = cf.pose_batch(list(range(n)), list(range(nmax, nmax + n)), False)
+        assert len(got2) == n
+    cf.close()
