@@ -139,6 +139,9 @@ int nik_pose(nik_ctx* ctx, nik_frame key, nik_frame cur, int not_large_rotation,
 /* n independent pairs (MapBuilder::Tracking over a batch, map_builder.cc:127-131). */
 int nik_pose_batch(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
                    int not_large_rotation, nik_pose_result* res);
+/* the same without waiting: res is final after nik_synchronize (or once two further calls have been enqueued) */
+int nik_pose_batch_async(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
+                         int not_large_rotation, nik_pose_result* res);
 
 /* The benchmark unit of SURVEY.md 8(d): for each of n pairs,
  *   ComputeIntermedium(current image) + ComputePose(key, current, not_large_rotation).

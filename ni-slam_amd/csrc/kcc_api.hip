@@ -1084,15 +1084,21 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     return NIK_OK;
 }
 
-int nik_pose_batch(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, int not_large_rotation,
-                   nik_pose_result* res) {
+int nik_pose_batch_async(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, int not_large_rotation,
+                         nik_pose_result* res) {
     if (!c || !keys || !curs || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
     int rc;
     if ((rc = check_kernel(c))) return rc;
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
-    if ((rc = pose_call(c, n, nullptr, keys, curs, not_large_rotation, res))) return rc;
+    return pose_call(c, n, nullptr, keys, curs, not_large_rotation, res);
+}
+
+int nik_pose_batch(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, int not_large_rotation,
+                   nik_pose_result* res) {
+    int rc = nik_pose_batch_async(c, n, keys, curs, not_large_rotation, res);
+    if (rc || n <= 0) return rc;
     return drain_all(c);
 }
 

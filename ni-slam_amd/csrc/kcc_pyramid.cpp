@@ -19,7 +19,9 @@ struct nik_pyramid {
     int levels = 0, max_batch = 0, H = 0, W = 0;
     std::vector<nik_ctx*> ctx;                 // [level]
     std::vector<int> h, w, pd, pc;
-    std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer)
+    std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer); d_cur[l] =
+                                               // d_key[l] + max_batch frames: one allocation, so that the key and the current
+                                               // frames of a level go through ONE intermedium call of 2n frames
     hipStream_t ds = nullptr;                  // the box-filter chain runs beside the levels' own streams
 };
 
@@ -29,7 +31,6 @@ void nik_pyramid_destroy(nik_pyramid* p) {
     if (!p) return;
     for (nik_ctx* c : p->ctx) if (c) nik_destroy(c);
     for (uint8_t* b : p->d_key) if (b) (void)hipFree(b);
-    for (uint8_t* b : p->d_cur) if (b) (void)hipFree(b);
     if (p->ds) (void)hipStreamDestroy(p->ds);
     delete p;
 }
@@ -48,12 +49,16 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
         c.rotation_divisor = cfg->rotation_divisor * num / den; c.rotation_channel = cfg->rotation_channel * num / den;
         c.height = H >> l; c.width = W >> l;
         p->h.push_back(H >> l); p->w.push_back(W >> l); p->pd.push_back(c.rotation_divisor); p->pc.push_back(c.rotation_channel);
-        int rc = nik_create(&c, H >> l, W >> l, max_batch, 2 * max_batch, device, &p->ctx[l]);
-        if (!rc) rc = nik_set_call_depth(p->ctx[l], 4);            // key spectra + current spectra + pose per batch, two batches in flight
+        // (contexts sized for 2 * max_batch frames per call: key and current frames of a level are transformed together; one
+        // stream per level -- batches this small lose more to the doubled launch count than a second stream gains)
+        int rc = nik_create(&c, H >> l, W >> l, 2 * max_batch, 2 * max_batch, device, &p->ctx[l]);
+        if (!rc) rc = nik_set_call_depth(p->ctx[l], 4);            // spectra + pose per batch, two batches in flight
+        if (!rc) rc = nik_set_streams(p->ctx[l], 1) == 1 ? 0 : NIK_ERR_INVALID_ARG;
         if (rc) { nik_pyramid_destroy(p); return rc; }
         if (l > 0) {
-            const size_t bytes = (size_t)max_batch * (H >> l) * (W >> l);
-            if (hipMalloc(&p->d_key[l], bytes) != hipSuccess || hipMalloc(&p->d_cur[l], bytes) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
+            const size_t frame = (size_t)(H >> l) * (W >> l);
+            if (hipMalloc(&p->d_key[l], 2 * frame * max_batch) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
+            p->d_cur[l] = p->d_key[l] + frame * max_batch;
         }
     }
     if (hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
@@ -81,24 +86,23 @@ int nik_pyramid_track_dev_async(nik_pyramid* p, int n, const uint8_t* d_key, con
     for (int l = 1; l < L; ++l) {
         if ((rc = nik_stream_wait_ctx(p->ctx[l], p->ds)) ||
             (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, key[l - 1], p->d_key[l], p->ds)) ||
-            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, cur[l - 1], p->d_cur[l], p->ds)) ||
+            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, cur[l - 1], p->d_key[l] + (size_t)n * p->h[l] * p->w[l], p->ds)) ||
             (rc = nik_ctx_wait_stream(p->ctx[l], p->ds))) return rc;
-        key[l] = p->d_key[l]; cur[l] = p->d_cur[l];
+        key[l] = p->d_key[l]; cur[l] = p->d_key[l] + (size_t)n * p->h[l] * p->w[l];
     }
-    std::vector<nik_frame> ks(n), cs(n);
-    for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; }
-    // key spectra of every level (independent of each other: the levels' streams overlap)
-    for (int l = L - 1; l >= 0; --l) if ((rc = nik_intermedium_batch_dev(p->ctx[l], n, key[l], ks.data()))) return rc;
+    // slots 0..n-1 hold the key frames, n..2n-1 the current frames; below level 0 both sets sit in one buffer (n frames
+    // apart only when n == max_batch, so the current frames are downsampled to d_key + n frames instead)
+    std::vector<nik_frame> ks(n), cs(n), all(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; all[i] = i; all[n + i] = n + i; }
+    for (int l = L - 1; l >= 1; --l) if ((rc = nik_intermedium_batch_dev(p->ctx[l], 2 * n, key[l], all.data()))) return rc;
+    if ((rc = nik_intermedium_batch_dev(p->ctx[0], n, key[0], ks.data())) ||
+        (rc = nik_intermedium_batch_dev(p->ctx[0], n, cur[0], cs.data()))) return rc;
     // coarsest level: plain KCC; finer levels: windows predicted on the device from the level above
     for (int l = L - 1; l >= 0; --l) {
         nik_ctx* c = p->ctx[l];
         nik_pose_result* out = res + (size_t)l * n;
-        if (l == L - 1) {
-            if ((rc = nik_track_batch_dev(c, n, cur[l], ks.data(), cs.data(), 1, out, 0))) return rc;
-        } else {
-            if ((rc = nik_intermedium_batch_dev(c, n, cur[l], cs.data())) ||
-                (rc = nik_pose_batch_chained(c, n, ks.data(), cs.data(), p->ctx[l + 1], radius, out, 0))) return rc;
-        }
+        if (l == L - 1) { if ((rc = nik_pose_batch_async(c, n, ks.data(), cs.data(), 1, out))) return rc; }
+        else if ((rc = nik_pose_batch_chained(c, n, ks.data(), cs.data(), p->ctx[l + 1], radius, out, 0))) return rc;
     }
     return NIK_OK;
 }
