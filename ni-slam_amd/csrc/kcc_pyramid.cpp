@@ -19,9 +19,9 @@ struct nik_pyramid {
     int levels = 0, max_batch = 0, H = 0, W = 0;
     std::vector<nik_ctx*> ctx;                 // [level]
     std::vector<int> h, w, pd, pc;
-    std::vector<uint8_t*> d_key, d_cur;        // [level >= 1] downsampled frames (level 0 is the caller's buffer); d_cur[l] =
-                                               // d_key[l] + max_batch frames: one allocation, so that the key and the current
-                                               // frames of a level go through ONE intermedium call of 2n frames
+    std::vector<uint8_t*> d_key;               // [level >= 1] downsampled frames, 2 * max_batch per level: the n key frames, then
+                                               // the n current frames, so that both go through ONE intermedium call of 2n frames
+                                               // (level 0 is the caller's buffers)
     hipStream_t ds = nullptr;                  // the box-filter chain runs beside the levels' own streams
 };
 
@@ -40,7 +40,7 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
     if ((H % (1 << levels)) || (W % (1 << levels))) return NIK_ERR_INVALID_ARG;      // every level keeps even sizes
     nik_pyramid* p = new nik_pyramid();
     p->levels = levels; p->max_batch = max_batch; p->H = H; p->W = W;
-    p->ctx.assign(levels, nullptr); p->d_key.assign(levels, nullptr); p->d_cur.assign(levels, nullptr);
+    p->ctx.assign(levels, nullptr); p->d_key.assign(levels, nullptr);
     for (int l = 0; l < levels; ++l) {
         nik_config c = *cfg;
         // polar geometry per level: 1, 2/3, 1/3, 1/6, ... of the base (720x480 -> 480x320 -> 240x160 -> 120x80)
@@ -58,7 +58,6 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
         if (l > 0) {
             const size_t frame = (size_t)(H >> l) * (W >> l);
             if (hipMalloc(&p->d_key[l], 2 * frame * max_batch) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
-            p->d_cur[l] = p->d_key[l] + frame * max_batch;
         }
     }
     if (hipStreamCreateWithFlags(&p->ds, hipStreamNonBlocking) != hipSuccess) { nik_pyramid_destroy(p); return NIK_ERR_HIP; }
