@@ -170,3 +170,29 @@ def test_gaussian_kernel_full_size():
             ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], PD)
             assert ok, "pair %d %s small_rot=%s: %s" % (i, motions[i], small_rot, msg)
     cf.close()
+
+
+def test_unique_pairs_parity_hd():
+    """BASELINE config 4's geometry (1280x720, the 1280-point 3-pass row plan and the 360-point column plan on image planes):
+    32 unique pairs through the batched device entry point, every one checked against the oracle; PSR at the tolerance of
+    planes above 1 MP (see test_gpu_parity)."""
+    import torch
+    N = nik()
+    Hh, Wh, n = 720, 1280, 32
+    cf = N.CorrelationFlow(N.default_config(), Hh, Wh, max_batch=n, max_frames=2 * n)
+    ocfg = ko.default_config()
+    keys, curs, motions = synth.make_unique_batch(n, Hh, Wh, seed0=31000, max_theta=8.0, max_shift=60, ncanvas=8)
+    poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True, nthreads=min(32, os.cpu_count() or 1))
+    dk = torch.from_numpy(keys).cuda(); dc = torch.from_numpy(curs).cuda(); torch.cuda.synchronize()
+    cf.intermedium_batch_dev(dk.data_ptr(), n, list(range(n)))
+    res = cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)
+    exact = 0
+    for i in range(n):
+        rerun = kcc_helpers.imposed_rerun(ocfg, Hh, Wh, keys[i], curs[i], True)
+        ok, ex, msg = check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], PD, psr_rtol=5e-3, rerun=rerun)
+        assert ok, "pair %d motion %s: %s" % (i, motions[i], msg)
+        exact += bool(ex)
+        cg, co = res[i].as_dict()["chosen"], dbgs[i]["chosen"]
+        assert res[i].as_dict()["trans_row"][cg] == dbgs[i]["trans_row"][co] and res[i].as_dict()["trans_col"][cg] == dbgs[i]["trans_col"][co]
+    print("hd: %d of %d rotation rows bit-identical, the rest accepted ties" % (exact, n))
+    cf.close()
