@@ -83,10 +83,14 @@ int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
 /* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
 int   nik_device(const nik_ctx* ctx);                        /* HIP device ordinal the context lives on */
-int   nik_device(const nik_ctx* ctx);
 /* A batched call is split over up to `n` concurrent HIP streams ("lanes", default 2 or $NIK_STREAMS, max 4);
  * returns the number now active.  Outputs do not depend on it. */
 int  nik_set_streams(nik_ctx* ctx, int n);
+/* A batched call of more than streams * `pairs` pairs is cut into chunks of at most `pairs` pairs, dealt to the streams in
+ * turn (0: one chunk per stream; default $NIK_CHUNK or the library's tuned value).  A chunk's intermediates stay in the
+ * 256 MiB Infinity Cache between the kernel that writes them and the one that reads them.  Outputs do not depend on it.
+ * Returns the previous value. */
+int  nik_set_chunk(nik_ctx* ctx, int pairs);
 int  nik_synchronize(nik_ctx* ctx);
 /* Per-keyframe cache of the key-side kernel Kzz = FFT(kernel(IFFT(|Z|^2))) and its max (both families), built the
  * first time a slot is used as a key and dropped when the slot is rewritten.  The reference recomputes Kzz in every
@@ -139,7 +143,7 @@ int nik_pose(nik_ctx* ctx, nik_frame key, nik_frame cur, int not_large_rotation,
 /* n independent pairs (MapBuilder::Tracking over a batch, map_builder.cc:127-131). */
 int nik_pose_batch(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
                    int not_large_rotation, nik_pose_result* res);
-/* the same without waiting: res is final after nik_synchronize (or once two further calls have been enqueued) */
+/* the same without waiting: res is final after nik_synchronize (or once as many further calls as the call depth -- 2 by default, nik_set_call_depth -- have been enqueued on every stream) */
 int nik_pose_batch_async(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
                          int not_large_rotation, nik_pose_result* res);
 
@@ -403,10 +407,16 @@ nik_ctx* nik_group_ctx(nik_group* g, int local_index);
 int  nik_group_rank(const nik_group* g, int local_index);
 /* contiguous shard [begin, end) of n units for `rank` of `world` (sizes differ by at most one; rank order = unit order) */
 void nik_group_shard(int n, int world, int rank, int* begin, int* end);
+/* the reference's winner rule (loop_closure.cc:61-65) over `world` gathered records of 8 doubles [score, global index (< 0:
+ * none), pose x3, info x3]: strictly larger score wins, equal scores go to the lowest rank = the first candidate in global
+ * order.  Returns the winning rank, -1 if no rank has a candidate.  Host-only (what nik_group_gather_best applies). */
+int  nik_group_pick_best(const double* records, int world);
+/* ranks the group's RCCL communicator spans (ncclCommCount); 0 = the group runs without RCCL (one member) */
+int  nik_group_comm_ranks(const nik_group* g);
 /* sum over the group of every member's latest-batch statistics (nik_set_residual_stats is switched on by the group),
  * reduced on the devices and all-reduced with RCCL; asynchronous when out == NULL (fetch with nik_group_residual_result) */
 int  nik_group_allreduce_residual(nik_group* g, double out[4]);
-int  nik_group_residual_result(nik_group* g, double out[4]);
+int  nik_group_residual_result(nik_group* g, double out[4]);      /* once per all-reduce: a second fetch is NIK_ERR_NOT_READY */
 /* every local member's best candidate (global index, -1: none) -> the group's winner by the reference's rule */
 int  nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_result* local_best, int* best_index, nik_pose_result* best);
 /* local groups: a batch of n pairs (host u8 images) sharded over the GPUs; keys[i] / cur_dst[i] are slots of the member

@@ -23,6 +23,7 @@
 using namespace kcc;
 
 enum { KCC_RING_MAX = 4 };
+enum { KCC_STATS_PARTS = 4096 };   // chunk partials of the residual statistics one API call may produce
 
 namespace {
 
@@ -58,6 +59,7 @@ struct Lane {
     unsigned long write_seq = 0;
     std::vector<unsigned long> seen;    // seen[w] = write_seq of lane w this lane has already waited for
     hipEvent_t tail_ev = nullptr;       // recorded at the end of the lane's latest call
+    int flip = 0;                       // item order of the lane's next big kernel (alternates: see Stage)
     unsigned long call_seq = 0;
     std::vector<unsigned long> seen_tail;   // seen_tail[r] = call_seq of lane r this lane has already waited for
     int cap_items = 0;
@@ -100,6 +102,8 @@ struct nik_ctx {
     int16_t* ud_map1 = nullptr; uint16_t* ud_map2 = nullptr;   // undistortion maps (nik_set_undistort); null = u8 inputs are already undistorted
     bool zz_half = true;          // uncached Kzz: transform only the Hermitian half of its kernel plane ($NIK_ZZ_HALF=0: off)
     bool fuse_polar = true;       // tracking path: fuse the polar spectrum's last pass into the pose's first kernel ($NIK_FUSE_POLAR=0: off)
+    bool alt_order = true;        // consecutive kernels of a lane walk the items in opposite directions ($NIK_ALT_ORDER=0: off)
+    int chunk_pairs = 0;          // batched calls are cut into chunks of at most this many pairs, dealt to the lanes in turn (0: one chunk per lane; $NIK_CHUNK)
     float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
     std::vector<uint8_t> slot_kzz;       // 1: cache valid
     std::vector<int8_t> slot_lane;       // lane that last wrote the slot (-1: none / host import)
@@ -112,6 +116,8 @@ struct nik_ctx {
     // residual statistics of the latest batch (nik_set_residual_stats): per-lane partials [4 lanes][4] + their sum [4], device
     // They are summed (and all-reduced, nik_group) on their own stream so that no lane waits for another.
     bool want_stats = false; double* d_stats = nullptr; double* h_stats = nullptr; int stats_lanes = 0;
+    int stats_parts = 0;                 // partial blocks [4] written by the chunks of the current API call (reset at API entry)
+    int last_pose_n = -1, last_pose_nhyp = 0, last_pose_nc = 0;   // shape of the latest pose call (nik_pose_batch_chained checks it)
     hipStream_t stats_stream = nullptr; hipEvent_t stats_done = nullptr; bool stats_pending = false;
     int graph_max = 0;                   // batches of <= graph_max pairs replay a captured hipGraph (0: off); $NIK_GRAPH
     hipEvent_t fence_ev = nullptr;       // nik_wait_for
@@ -399,6 +405,9 @@ int ensure_f32_images(nik_ctx* c, Lane& L, int li, int n, const nik_frame* slots
 struct Stage {
     nik_ctx* c; hipStream_t s; int rec = -1;
     Stage(nik_ctx* c_, Lane& L, const char* name, double bytes) : c(c_), s(L.stream) {
+        // every big kernel of a lane consumes what the previous one produced: alternate the item order so that it starts
+        // with the items written last (still in the Infinity Cache)
+        if (c->alt_order) { set_launch_reverse(L.flip); L.flip ^= 1; }
         if (!c->prof_on) return;
         int id = -1;
         for (size_t i = 0; i < c->prof_stats.size(); ++i) if (c->prof_stats[i].name == name) { id = (int)i; break; }
@@ -412,7 +421,7 @@ struct Stage {
         (void)hipEventRecord(r.a, s);
         c->prof_recs.push_back(r); rec = (int)c->prof_recs.size() - 1;
     }
-    ~Stage() { if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, s); }
+    ~Stage() { set_launch_reverse(0); if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, s); }
 };
 std::string kname(const char* base, int len, const char* mode) {
     char b[64]; snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode); return b;
@@ -669,6 +678,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
     if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
     if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
+    if (const char* e = getenv("NIK_ALT_ORDER")) c->alt_order = atoi(e) != 0;
+    if (const char* e = getenv("NIK_CHUNK")) c->chunk_pairs = std::max(0, atoi(e));
     if (const char* e = getenv("NIK_GRAPH")) c->graph_max = std::max(0, atoi(e));
     c->slot_kind.assign(max_frames, 0);
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
@@ -723,18 +734,25 @@ int nik_set_streams(nik_ctx* c, int n) {
     return c->active_lanes;
 }
 
+int nik_set_chunk(nik_ctx* c, int pairs) {
+    if (!c || pairs < 0) return NIK_ERR_INVALID_ARG;
+    const int old = c->chunk_pairs;
+    c->chunk_pairs = pairs;
+    return old;
+}
+
 int nik_set_residual_stats(nik_ctx* c, int enable) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc = drain_all(c);
     if (rc) return rc;
     if (enable && !c->d_stats) {
-        HIP_TRY(c, hipMalloc(&c->d_stats, sizeof(double) * 4 * 5));           // 4 lane partials + the total
-        HIP_TRY(c, hipMemset(c->d_stats, 0, sizeof(double) * 4 * 5));
+        HIP_TRY(c, hipMalloc(&c->d_stats, sizeof(double) * 4 * (KCC_STATS_PARTS + 1)));           // chunk partials + the total
+        HIP_TRY(c, hipMemset(c->d_stats, 0, sizeof(double) * 4 * (KCC_STATS_PARTS + 1)));
         HIP_TRY(c, hipHostMalloc(&c->h_stats, sizeof(double) * 4));
         HIP_TRY(c, hipStreamCreateWithFlags(&c->stats_stream, hipStreamNonBlocking));
         HIP_TRY(c, hipEventCreateWithFlags(&c->stats_done, hipEventDisableTiming));
     }
-    c->want_stats = enable != 0; c->stats_lanes = 0;
+    c->want_stats = enable != 0; c->stats_lanes = 0; c->stats_parts = 0;
     return NIK_OK;
 }
 
@@ -743,11 +761,11 @@ int nik_residual_stats_dev(nik_ctx* c, double** d_total, void** stream) {
     if (!c || !d_total) return NIK_ERR_INVALID_ARG;
     if (!c->want_stats) return fail(c, NIK_ERR_NOT_READY, "residual statistics are off (nik_set_residual_stats)");
     for (int li = 0; li < c->stats_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->stats_stream, c->lanes[li].tail_ev, 0));
-    launch_stats_sum(c->stats_stream, c->d_stats, c->stats_lanes, c->d_stats + 16);
+    launch_stats_sum(c->stats_stream, c->d_stats, c->stats_parts, c->d_stats + 4 * KCC_STATS_PARTS);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventRecord(c->stats_done, c->stats_stream));
     c->stats_pending = true;
-    *d_total = c->d_stats + 16;
+    *d_total = c->d_stats + 4 * KCC_STATS_PARTS;
     if (stream) *stream = (void*)c->stats_stream;
     return NIK_OK;
 }
@@ -986,10 +1004,22 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
-    if (upper && lanes_for(upper, n) != nl) return fail(c, NIK_ERR_INVALID_ARG, "chained levels must split the batch over the same number of streams");
-    c->stats_lanes = 0;
-    for (int li = 0; li < nl; ++li) {
-        int b, e; chunk_of(n, nl, li, b, e);
+    // chunks: one per lane, or -- $NIK_CHUNK / nik_set_chunk -- pieces of at most chunk_pairs pairs dealt to the lanes in turn.
+    // Small chunks keep a kernel's output in the 256 MiB Infinity Cache until the next kernel of the lane reads it.
+    int nc = nl;
+    if (c->chunk_pairs > 0 && !upper && n > nl * c->chunk_pairs) nc = ((n + c->chunk_pairs - 1) / c->chunk_pairs + nl - 1) / nl * nl;
+    if (upper) {
+        // the windows come from upper's latest pose call: it must have been a one-hypothesis call over the same n pairs,
+        // cut into the same chunks (else the predicted centres would be stale or belong to other pairs)
+        if (upper->last_pose_n != n || upper->last_pose_nhyp != 1 || upper->last_pose_nc != nc || lanes_for(upper, n) != nl)
+            return fail(c, NIK_ERR_NOT_READY, "chained call: the upper level's latest pose call does not match (n %d/%d, hypotheses %d, chunks %d/%d)",
+                        upper->last_pose_n, n, upper->last_pose_nhyp, upper->last_pose_nc, nc);
+    }
+    if (c->want_stats && c->stats_parts + nc > KCC_STATS_PARTS) return fail(c, NIK_ERR_CAPACITY, "residual statistics: more than %d chunks in one call", (int)KCC_STATS_PARTS);
+    c->last_pose_n = n; c->last_pose_nhyp = not_large_rotation ? 1 : 2; c->last_pose_nc = nc;
+    for (int ci = 0; ci < nc; ++ci) {
+        const int li = ci % nl;
+        int b, e; chunk_of(n, nc, ci, b, e);
         const int m = e - b; if (m <= 0) continue;
         Lane& L = c->lanes[li];
         if ((rc = begin_call(c, L))) return rc;
@@ -1001,7 +1031,8 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
         }
         // Small stored-frame batches are latency-bound by their ~16 dependent launches: replay them as one hipGraph (index
         // upload, kernels and result copies captured once per (ring entry, n, mode); all pointers are call-invariant).
-        bool graphable = c->graph_max > 0 && !d_gray && !upper && !win_centers && nl == 1 && m <= c->graph_max && !c->prof_on;
+        bool graphable = c->graph_max > 0 && !d_gray && !upper && !win_centers && nl == 1 && nc == 1 && m <= c->graph_max && !c->prof_on &&
+                         !(c->want_stats && c->stats_parts != 0);
         if (graphable) for (int i = b; i < e; ++i) if (!(c->slot_kind[curs[i]] & 1)) graphable = false;
         Lane::PoseGraph* pg = nullptr;
         const int gslot = (int)(L.cur - L.ring), gflags = (not_large_rotation ? 1 : 0) | (c->want_stats ? 2 : 0) | (c->kzz_cache ? 4 : 0);
@@ -1023,7 +1054,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
                 rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, false);
                 if (!rc) rc = enqueue_pose(c, L, m, not_large_rotation, true, false, -1);
                 if (!rc && c->want_stats)
-                    launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, n_hyp, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
+                    launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, n_hyp, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * (size_t)c->stats_parts);
                 const hipError_t ce = hipStreamEndCapture(L.stream, &graph);
                 if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
                 HIP_TRY(c, ce);
@@ -1031,7 +1062,11 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
                 (void)hipGraphDestroy(graph);
                 pg->exec = exec; (void)slot; (void)flags;
             }
-            if (c->want_stats) { if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0)); c->stats_lanes = std::max(c->stats_lanes, li + 1); }
+            if (c->want_stats) {
+                // (the captured statistics kernel writes the part slot it was captured with: graphs are only used with one chunk per call)
+                if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0));
+                c->stats_parts += 1; c->stats_lanes = std::max(c->stats_lanes, li + 1);
+            }
             HIP_TRY(c, hipGraphLaunch(pg->exec, L.stream));
             pg->uses += 1;
         } else {
@@ -1072,8 +1107,8 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             if ((rc = enqueue_pose(c, L, m, not_large_rotation, img_u8, fuse, (win_centers || upper) ? win_radius : -1))) return rc;
             if (c->want_stats) {                                  // this lane's share of the batch's residual statistics
                 if (c->stats_pending) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->stats_done, 0));   // (the previous batch's partials are consumed)
-                launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, not_large_rotation ? 1 : 2, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * li);
-                c->stats_lanes = std::max(c->stats_lanes, li + 1);
+                launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, not_large_rotation ? 1 : 2, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * (size_t)c->stats_parts);
+                c->stats_parts += 1; c->stats_lanes = std::max(c->stats_lanes, li + 1);
             }
             if (fuse && (rc = mark_written(c, L, li, curs + b, m, 1))) return rc;
         }
@@ -1092,6 +1127,7 @@ int nik_pose_batch_async(nik_ctx* c, int n, const nik_frame* keys, const nik_fra
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
+    c->stats_parts = 0; c->stats_lanes = 0;
     return pose_call(c, n, nullptr, keys, curs, not_large_rotation, res);
 }
 
@@ -1115,6 +1151,7 @@ int nik_pose_batch_window(nik_ctx* c, int n, const nik_frame* keys, const nik_fr
         if (w[0] < 0 || w[0] >= c->PD || w[1] < 0 || w[1] >= c->PC || w[2] < 0 || w[2] >= c->H || w[3] < 0 || w[3] >= c->W)
             return fail(c, NIK_ERR_INVALID_ARG, "window centre of pair %d outside its surface", i);
     }
+    c->stats_parts = 0; c->stats_lanes = 0;
     if ((rc = pose_call(c, n, nullptr, keys, curs, 1, res, centers, radius))) return rc;
     return drain_all(c);
 }
@@ -1130,6 +1167,7 @@ int nik_pose_batch_chained(nik_ctx* c, int n, const nik_frame* keys, const nik_f
     if (n == 0) return NIK_OK;
     if (n > c->max_batch) return fail(c, NIK_ERR_CAPACITY, "batch %d exceeds max_batch %d", n, c->max_batch);
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, keys[i], true)) || (rc = check_slot(c, curs[i], true))) return rc;
+    c->stats_parts = 0; c->stats_lanes = 0;
     if ((rc = pose_call(c, n, nullptr, keys, curs, 1, res, nullptr, radius, upper))) return rc;
     return sync ? drain_all(c) : NIK_OK;
 }
@@ -1231,6 +1269,7 @@ int nik_track_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const nik_fram
             mark[cur_dst[i]] = 2;
         }
     }
+    c->stats_parts = 0; c->stats_lanes = 0;
     if ((rc = pose_call(c, n, d_gray, keys, cur_dst, not_large_rotation, res))) return rc;
     return sync ? drain_all(c) : NIK_OK;
 }
@@ -1261,6 +1300,7 @@ int nik_match(nik_ctx* c, nik_frame query, int n, const nik_frame* cands, int* b
     // ComputePose(cand_i, query, not_large_rotation=false) for every candidate (loop_closure.cc:58-59), max_batch at a time;
     // the chunks are queued back to back (two in flight per lane) and finalised by the drain
     std::vector<nik_frame> curs(std::min(n, c->max_batch), query);
+    c->stats_parts = 0; c->stats_lanes = 0;      // the statistics cover every chunk of this search
     for (int b = 0; b < n; b += c->max_batch) {
         const int m = std::min(c->max_batch, n - b);
         if ((rc = pose_call(c, m, nullptr, cands + b, curs.data(), 0, res + b))) return rc;

@@ -16,12 +16,26 @@
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>      // types and enums only; every function is resolved with dlsym
+#else
+// RCCL's headers are absent: declare the handful of types the entry points use (ABI of rccl.h / nccl.h 2.x), so that the
+// library still builds; at run time rccl() then reports "RCCL not found" unless a librccl can be dlopen-ed after all
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclChar = 0, ncclUint8 = 1, ncclInt32 = 2, ncclInt = 2, ncclUint32 = 3, ncclInt64 = 4, ncclUint64 = 5,
+               ncclFloat16 = 6, ncclHalf = 6, ncclFloat32 = 7, ncclFloat = 7, ncclFloat64 = 8, ncclDouble = 8 } ncclDataType_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 } ncclRedOp_t;
+}
+#endif
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -34,6 +48,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
@@ -43,24 +58,26 @@ struct Rccl {
     bool ok = false;
 };
 
+static void rccl_load(Rccl& r);
 Rccl& rccl() {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r;
-    tried = true;
+    static std::once_flag once;                 // (two threads creating groups at once must not race the dlopen / dlsym)
+    std::call_once(once, [] { rccl_load(r); });
+    return r;
+}
+static void rccl_load(Rccl& r) {
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);          // reuse a copy the host process already loaded
         if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
     }
-    if (!r.lib) { r.err = std::string("RCCL not found: ") + (dlerror() ? dlerror() : "librccl.so.1"); return r; }
-#define SYM(field, sym) do { *(void**)(&r.field) = dlsym(r.lib, sym); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; return r; } } while (0)
+    if (!r.lib) { const char* de = dlerror(); r.err = std::string("RCCL not found: ") + (de ? de : "librccl.so.1"); return; }
+#define SYM(field, sym) do { *(void**)(&r.field) = dlsym(r.lib, sym); if (!r.field) { r.err = std::string("RCCL symbol missing: ") + sym; return; } } while (0)
     SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommInitAll, "ncclCommInitAll");
-    SYM(CommDestroy, "ncclCommDestroy"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
+    SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
     r.ok = true;
-    return r;
 }
 
 thread_local std::string g_group_error;
@@ -130,6 +147,25 @@ void nik_group_shard(int n, int world, int rank, int* begin, int* end) {
     const int b = rank * base + std::min(rank, rem);
     if (begin) *begin = b;
     if (end) *end = b + base + (rank < rem ? 1 : 0);
+}
+
+// The reference's winner rule over the gathered records (loop_closure.cc:61-65): records[8 r] = response.sum() of rank r's best
+// candidate, records[8 r + 1] = its global index (< 0: rank r has none).  A strictly larger score wins, so among equal scores
+// the lowest rank -- ranks hold contiguous shards in candidate order -- i.e. the first candidate in global order.  Returns
+// the winning RANK (-1: no candidate anywhere).  Host-only.
+int nik_group_pick_best(const double* records, int world) {
+    int bi = -1; double bs = -3.0;                                   // LoopClosureResult(): response(-1,-1,-1)  (loop_closure.h:14)
+    for (int r = 0; r < world; ++r)
+        if (records[8 * r + 1] >= 0 && records[8 * r] > bs) { bs = records[8 * r]; bi = r; }
+    return bi;
+}
+
+// number of ranks the group's RCCL communicator really spans (ncclCommCount); 0 when the group runs without RCCL
+// (a single member, $NIK_GROUP_FORCE_RCCL unset) -- a machine-checkable fact for bench.py's JSON line
+int nik_group_comm_ranks(const nik_group* g) {
+    if (!g || !g->use_rccl || g->m.empty() || !g->m[0].comm || !rccl().ok) return 0;
+    int n = 0;
+    return rccl().CommCount(g->m[0].comm, &n) == ncclSuccess ? n : -1;
 }
 
 int nik_group_unique_id(uint8_t id[NIK_GROUP_ID_BYTES]) {
@@ -236,14 +272,24 @@ int nik_group_allreduce_residual(nik_group* g, double out[4]) {
         if (rc) return gfail(g, rc, std::string("nik_residual_stats_dev: ") + nik_last_error(mb.ctx));
         mb.stream = (hipStream_t)st;
     }
+    // (an error inside the RCCL group must not leave it open -- every later collective of the process would be deferred
+    // for ever: remember the first error, always close the group, then report)
+    std::string first_err;
     if (multi) G_NCCL(g, rccl().GroupStart());
-    for (size_t i = 0; i < g->m.size(); ++i) {
+    for (size_t i = 0; i < g->m.size() && first_err.empty(); ++i) {
         Member& mb = g->m[i];
-        G_HIP(g, hipSetDevice(mb.device));
-        if (multi) G_NCCL(g, rccl().AllReduce(src[i], mb.d_buf, 4, ncclDouble, ncclSum, mb.comm, mb.stream));
-        else G_HIP(g, hipMemcpyAsync(mb.d_buf, src[i], sizeof(double) * 4, hipMemcpyDeviceToDevice, mb.stream));
+        hipError_t he = hipSetDevice(mb.device);
+        if (he != hipSuccess) { first_err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+        if (multi) {
+            const ncclResult_t nr = rccl().AllReduce(src[i], mb.d_buf, 4, ncclDouble, ncclSum, mb.comm, mb.stream);
+            if (nr != ncclSuccess) first_err = std::string("ncclAllReduce: ") + rccl().GetErrorString(nr);
+        } else {
+            he = hipMemcpyAsync(mb.d_buf, src[i], sizeof(double) * 4, hipMemcpyDeviceToDevice, mb.stream);
+            if (he != hipSuccess) first_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he);
+        }
     }
-    if (multi) G_NCCL(g, rccl().GroupEnd());
+    if (multi) { const ncclResult_t nr = rccl().GroupEnd(); if (nr != ncclSuccess && first_err.empty()) first_err = std::string("ncclGroupEnd: ") + rccl().GetErrorString(nr); }
+    if (!first_err.empty()) return gfail(g, NIK_ERR_HIP, first_err);
     Member& m0 = g->m[0];
     G_HIP(g, hipSetDevice(m0.device));
     G_HIP(g, hipMemcpyAsync(m0.h_buf, m0.d_buf, sizeof(double) * 4, hipMemcpyDeviceToHost, m0.stream));
@@ -257,6 +303,7 @@ int nik_group_residual_result(nik_group* g, double out[4]) {
     if (!g->stats_inflight) return gfail(g, NIK_ERR_NOT_READY, "no all-reduce in flight");
     G_HIP(g, hipEventSynchronize(g->m[0].done));
     memcpy(out, g->m[0].h_buf, sizeof(double) * 4);
+    g->stats_inflight = false;                   // fetched: a second fetch without a new all-reduce is an error, not stale data
     return NIK_OK;
 }
 
@@ -280,22 +327,28 @@ int nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_
         }
         G_HIP(g, hipMemcpyAsync(mb.d_buf + 4, rec, sizeof(double) * 8, hipMemcpyHostToDevice, mb.own_stream));
     }
+    std::string first_err;
     if (multi) G_NCCL(g, rccl().GroupStart());
-    for (size_t i = 0; i < g->m.size(); ++i) {
+    for (size_t i = 0; i < g->m.size() && first_err.empty(); ++i) {
         Member& mb = g->m[i];
-        G_HIP(g, hipSetDevice(mb.device));
-        if (multi) G_NCCL(g, rccl().AllGather(mb.d_buf + 4, mb.d_buf + 12, 8, ncclDouble, mb.comm, mb.own_stream));
-        else G_HIP(g, hipMemcpyAsync(mb.d_buf + 12, mb.d_buf + 4, sizeof(double) * 8, hipMemcpyDeviceToDevice, mb.own_stream));
+        hipError_t he = hipSetDevice(mb.device);
+        if (he != hipSuccess) { first_err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+        if (multi) {
+            const ncclResult_t nr = rccl().AllGather(mb.d_buf + 4, mb.d_buf + 12, 8, ncclDouble, mb.comm, mb.own_stream);
+            if (nr != ncclSuccess) first_err = std::string("ncclAllGather: ") + rccl().GetErrorString(nr);
+        } else {
+            he = hipMemcpyAsync(mb.d_buf + 12, mb.d_buf + 4, sizeof(double) * 8, hipMemcpyDeviceToDevice, mb.own_stream);
+            if (he != hipSuccess) first_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he);
+        }
     }
-    if (multi) G_NCCL(g, rccl().GroupEnd());
+    if (multi) { const ncclResult_t nr = rccl().GroupEnd(); if (nr != ncclSuccess && first_err.empty()) first_err = std::string("ncclGroupEnd: ") + rccl().GetErrorString(nr); }
+    if (!first_err.empty()) return gfail(g, NIK_ERR_HIP, first_err);
     Member& m0 = g->m[0];
     G_HIP(g, hipSetDevice(m0.device));
     G_HIP(g, hipMemcpyAsync(m0.h_buf + 12, m0.d_buf + 12, sizeof(double) * W8, hipMemcpyDeviceToHost, m0.own_stream));
     for (Member& mb : g->m) { G_HIP(g, hipSetDevice(mb.device)); G_HIP(g, hipStreamSynchronize(mb.own_stream)); }
     const double* all = m0.h_buf + 12;
-    int bi = -1; double bs = -3.0;                                   // LoopClosureResult(): response(-1,-1,-1)  (loop_closure.h:14)
-    for (int r = 0; r < g->world; ++r)                               // rank order == global candidate order (contiguous shards)
-        if (all[8 * r + 1] >= 0 && all[8 * r] > bs) { bs = all[8 * r]; bi = r; }
+    const int bi = nik_group_pick_best(all, g->world);
     *best_index = bi >= 0 ? (int)all[8 * bi + 1] : -1;
     if (best && bi >= 0) {
         memset(best, 0, sizeof(*best));

@@ -122,6 +122,8 @@ void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, con
                           float* S, size_t s_stride, int need_cols = 0);
 // RemoveZeroComponent patch of the shifted planes (one workgroup per item)
 void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W);
+// item order of the A / B kernels launched next by this host thread: 0 = front to back, 1 = back to front (speed only)
+void set_launch_reverse(int rev);
 void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W);
 // inverse -> /(rows*cols) -> kernel function -> running max|k| -> forward; in place on `buf`.
 // buf holds 2 planes per item (zz then xz), maxbuf 2 uints per item (float bits, zeroed by caller),

@@ -133,7 +133,10 @@ __device__ __forceinline__ float kernel_value(const KernelFn& fn, float xz, floa
 
 // Workgroups of one item share its source plane (gathers): put them on the same XCD (the dispatcher places
 // linear block b on XCD b % 8), so the plane is fetched into one L2 instead of eight.  Speed only.
-__device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& item) {
+// rev: walk the items back to front.  Consecutive kernels of a lane alternate the direction (set_launch_reverse), so a
+// consumer starts with the items its producer wrote LAST -- the ones still in the 256 MiB Infinity Cache
+// (tools/probes/mall_order_probe.hip: +22 % on a copy chain whose planes are about the cache's size).  Speed only.
+__device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& item, int rev = 0) {
     const int L = blockIdx.x;
     const int full_items = (n_items / 8) * 8;
     if (L < full_items * nbx) {
@@ -145,7 +148,10 @@ __device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& i
         item = full_items + r / nbx;
         bx = r % nbx;
     }
+    if (rev) item = n_items - 1 - item;
 }
+static thread_local int g_launch_rev = 0;
+void set_launch_reverse(int rev) { g_launch_rev = rev ? 1 : 0; }
 
 // ------------------------------------------------------------------------------------------------
 // u8 row-major -> f32 column-major, /255  (utils.cc:110-118)
@@ -325,7 +331,7 @@ enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
 struct AArgs {
-    int rows, cols, hr, n_items, ablate;
+    int rows, cols, hr, n_items, ablate, rev;
     const float2* tw_f; const float2* tw_i; const float2* tw_full;
     const float2* twI_f; const float2* twI_i;                // tables of PlanInv (spectrum-in kernels)
     // forward source
@@ -582,8 +588,9 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
         // gather tables (L2-resident), and every item's annulus is read exactly once
         const int nbx = a.cols / A_LX;
         bx = nbx - 1 - (int)(blockIdx.x / (unsigned)a.n_items); item = (int)(blockIdx.x % (unsigned)a.n_items);
+        if (a.rev) item = a.n_items - 1 - item;
     } else {
-        xcd_coords(a.cols / A_LX, a.n_items, bx, item);
+        xcd_coords(a.cols / A_LX, a.n_items, bx, item, a.rev);
     }
     const int x0 = bx * A_LX;
 
@@ -798,7 +805,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
     float2* lds = reinterpret_cast<float2*>(smem);
     if (ABL(a, 8)) return;
     int g, item;
-    xcd_coords((a.cols / A_LX) / tpw, a.n_items, g, item);           // groups of tpw tiles; an image's groups share an XCD
+    xcd_coords((a.cols / A_LX) / tpw, a.n_items, g, item, a.rev);           // groups of tpw tiles; an image's groups share an XCD
     const uint8_t* in = a.src8 + (size_t)item * a.src8_stride;
     uint8_t* keep = a.dst8 ? a.dst8 + (size_t)a.dst8_slot[item] * a.dst8_stride : nullptr;
     uint4 cur[NR], nxt[NR];
@@ -889,16 +896,16 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
         // Kzz's kernel plane is real and even (an autocorrelation), so its column W-c is the y-reversed column c and
         // transforms to the conjugate: only the columns <= W/2 of plane 0 are processed (solve_inv mirrors the rest)
         int t;
-        xcd_coords(a.zz_tiles + nbx, a.n_items, t, item);
+        xcd_coords(a.zz_tiles + nbx, a.n_items, t, item, a.rev);
         plane = t < a.zz_tiles ? 0 : 1;
         bx = plane ? t - a.zz_tiles : t;
     } else if (EPI == EPI_SHIFTED && a.zz_tiles > 0) {
         // IFFT(|F|) is real and even as well: only the column tiles covering [0, W/2] are transformed, each column is
         // also written to its mirror position (see the epilogue)
-        xcd_coords(a.zz_tiles, a.n_items, bx, item);
+        xcd_coords(a.zz_tiles, a.n_items, bx, item, a.rev);
         plane = 0;
     } else {
-        xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2);
+        xcd_coords(nbx, a.n_items * (KFWD ? a.n_planes : 1), bx, item2, a.rev);
         item = KFWD ? item2 / a.n_planes : item2;
         plane = KFWD ? a.plane_first + item2 % a.n_planes : 0;
     }
@@ -1106,7 +1113,7 @@ template <int HH> static void polar_launch(hipStream_t s, int n_items, const AAr
 }
 static AArgs base_args(PlaneGeom g, Tables t) {
     AArgs a{};
-    a.ablate = ablate_flags(); a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full; a.twI_f = t.halfI_f; a.twI_i = t.halfI_i;
+    a.ablate = ablate_flags(); a.rev = g_launch_rev; a.rows = g.rows; a.cols = g.cols; a.hr = g.hr; a.tw_f = t.half_f; a.tw_i = t.half_i; a.tw_full = t.tw_full; a.twI_f = t.halfI_f; a.twI_i = t.halfI_i;
     return a;
 }
 
@@ -1243,7 +1250,7 @@ enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_I
        B_ZZ_INV = 6, B_MUL_INV_X = 7, B_FWD_MUL_INV_X = 8, B_SOLVE_CACHED = 9 };
 
 struct BArgs {
-    int cols, hr, ablate;
+    int cols, hr, ablate, rev;
     const float2* tw_f; const float2* tw_i;
     const float2* src; size_t src_stride; const int* src_idx;     // primary input
     const float2* zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
@@ -1322,7 +1329,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     float2* lds = reinterpret_cast<float2*>(smem);
     if (ABL(a, 8)) return;
     const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
-    const int item = blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
+    const int item = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
     const bool valid0 = k < a.hr;
     const bool valid = valid0 && !ABL(a, 1);          // loads
     const bool vst = valid0 && !ABL(a, 2);            // stores
@@ -1442,8 +1449,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         const int zslot = a.z_idx[item];
         load_strided(vin[0], a.src + (size_t)item * a.src_stride + a.in_plane_stride + loff, DF::MF, valid && j < DF::MF);
         load_strided(kz, a.kzz + (size_t)zslot * a.kzz_stride + loff, DF::ML, valid && j < DF::ML);
-        const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.mzz[zslot]));
-        const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
+        const float rzz = 1.0f / __uint_as_float(a.mzz[zslot]);
+        const float rxz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 1]);
         if (!nofft) fft_chain<P, false, 1>(vin, kx, j, ex1, a.tw_f);
         static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
@@ -1451,7 +1458,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         for (int q = 0; q < DF::RL; ++q) {
             const float2 den = make_float2(kz[q].x * rzz + a.lambda, kz[q].y * rzz);
             const float2 num = make_float2(kx[0][q].x * rxz, kx[0][q].y * rxz);
-            const float inv = sg * __builtin_amdgcn_rcpf(den.x * den.x + den.y * den.y);
+            const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
             const float2 gg = cmulc(num, den);
             g[0][q] = make_float2(gg.x * inv, gg.y * inv);
         }
@@ -1480,8 +1487,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             load_strided(vin[0], src, DF::MF, valid && j < DF::MF);
         }
         load_strided(vin[1], src + a.in_plane_stride, DF::MF, valid && j < DF::MF);
-        const float rzz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 0]));
-        const float rxz = __builtin_amdgcn_rcpf(__uint_as_float(a.maxbuf[2 * item + 1]));
+        const float rzz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 0]);
+        const float rxz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 1]);
         if (!nofft) {
             if (C::SEQ) {
                 float2 (&v0)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[0]); float2 (&v1)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[1]);
@@ -1500,7 +1507,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         for (int q = 0; q < DF::RL; ++q) {
             const float2 den = make_float2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
             const float2 num = make_float2(kk[1][q].x * rxz, kk[1][q].y * rxz);
-            const float inv = sg * __builtin_amdgcn_rcpf(den.x * den.x + den.y * den.y);
+            const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
             const float2 gg = cmulc(num, den);
             g[0][q] = make_float2(gg.x * inv, gg.y * inv);
         }
@@ -1541,7 +1548,7 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
 
 static BArgs base_bargs(PlaneGeom g, Tables t) {
     BArgs a{};
-    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = ablate_flags();
+    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = ablate_flags(); a.rev = g_launch_rev;
     return a;
 }
 

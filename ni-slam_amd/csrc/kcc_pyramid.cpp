@@ -49,9 +49,11 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
         c.rotation_divisor = cfg->rotation_divisor * num / den; c.rotation_channel = cfg->rotation_channel * num / den;
         c.height = H >> l; c.width = W >> l;
         p->h.push_back(H >> l); p->w.push_back(W >> l); p->pd.push_back(c.rotation_divisor); p->pc.push_back(c.rotation_channel);
-        // (contexts sized for 2 * max_batch frames per call: key and current frames of a level are transformed together; one
-        // stream per level -- batches this small lose more to the doubled launch count than a second stream gains)
-        int rc = nik_create(&c, H >> l, W >> l, 2 * max_batch, 2 * max_batch, device, &p->ctx[l]);
+        // (below level 0 the contexts are sized for 2 * max_batch frames per call: key and current frames of a level are
+        // transformed together.  Level 0 -- whose buffers are the big ones -- never runs a 2n-frame call: its key and current
+        // frames arrive in two caller buffers and go through two n-frame calls, so max_batch items with 2 * max_batch slots do.
+        // One stream per level: batches this small lose more to the doubled launch count than a second stream gains)
+        int rc = nik_create(&c, H >> l, W >> l, l == 0 ? max_batch : 2 * max_batch, 2 * max_batch, device, &p->ctx[l]);
         if (!rc) rc = nik_set_call_depth(p->ctx[l], 4);            // spectra + pose per batch, two batches in flight
         if (!rc) rc = nik_set_streams(p->ctx[l], 1) == 1 ? 0 : NIK_ERR_INVALID_ARG;
         if (rc) { nik_pyramid_destroy(p); return rc; }
@@ -89,8 +91,8 @@ int nik_pyramid_track_dev_async(nik_pyramid* p, int n, const uint8_t* d_key, con
             (rc = nik_ctx_wait_stream(p->ctx[l], p->ds))) return rc;
         key[l] = p->d_key[l]; cur[l] = p->d_key[l] + (size_t)n * p->h[l] * p->w[l];
     }
-    // slots 0..n-1 hold the key frames, n..2n-1 the current frames; below level 0 both sets sit in one buffer (n frames
-    // apart only when n == max_batch, so the current frames are downsampled to d_key + n frames instead)
+    // slots 0..n-1 hold the key frames, n..2n-1 the current frames; below level 0 both sets sit in one buffer, the current
+    // frames directly behind the n key frames (d_key + n frames), so one 2n-frame call transforms them all
     std::vector<nik_frame> ks(n), cs(n), all(2 * (size_t)n);
     for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; all[i] = i; all[n + i] = n + i; }
     for (int l = L - 1; l >= 1; --l) if ((rc = nik_intermedium_batch_dev(p->ctx[l], 2 * n, key[l], all.data()))) return rc;

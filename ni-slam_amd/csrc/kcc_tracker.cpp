@@ -113,6 +113,10 @@ struct nik_tracker {
             }
             const int rc = nik_pose_graph_optimize((int)ids.size(), ids.data(), poses.data(), (int)cons.size(), cons.data(), 0, &last_summary);
             if (rc) { map_rc = rc; }
+            // the solver also returns NIK_OK when its trust region collapsed (termination FAILURE): the reference CHECK-fails on an
+            // unusable solution (OptimizeMap -> SolveOptimizationProblem, map_builder.cc:263-277); here the old poses are kept
+            // and the error is reported through the push
+            else if (last_summary.termination == NIK_PG_FAILURE) { map_rc = NIK_ERR_INVALID_ARG; }
             else {
                 for (size_t i = 0; i < kf_poses.size(); ++i) for (int k = 0; k < 3; ++k) kf_poses[i][k] = poses[3 * i + k];
                 if (map) map_rc = nik_map_update_poses(map, (int)ids.size(), ids.data(), poses.data());      // Map::UpdatePoses (map.cc:73-79)

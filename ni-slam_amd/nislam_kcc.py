@@ -24,7 +24,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_intermedium_u8", "nik_intermedium_f32", "nik_intermedium_batch_dev", "nik_frame_export",
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar", "nik_dbg_response",
-           "nik_profile_enable", "nik_profile_read", "nik_set_streams",
+           "nik_profile_enable", "nik_profile_read", "nik_set_streams", "nik_set_chunk",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
@@ -33,7 +33,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
            "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
-           "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard",
+           "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard", "nik_group_pick_best", "nik_group_comm_ranks",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
            "nik_group_match"]
 
@@ -137,6 +137,7 @@ def load():
         L.nik_stream.restype = P
         L.nik_synchronize.argtypes = [P]
         L.nik_set_streams.argtypes = [P, I]
+        L.nik_set_chunk.argtypes = [P, I]
         L.nik_set_kzz_cache.argtypes = [P, I]
         L.nik_camera_maps.argtypes = [P, P, I, I, P, P, P]
         L.nik_tracker_attach_map.argtypes = [P, P, I]
@@ -222,6 +223,8 @@ def load():
         L.nik_group_rank.argtypes = [P, I]
         L.nik_group_shard.argtypes = [I, I, I, P, P]
         L.nik_group_shard.restype = None
+        L.nik_group_pick_best.argtypes = [P, I]
+        L.nik_group_comm_ranks.argtypes = [P]
         L.nik_group_allreduce_residual.argtypes = [P, P]
         L.nik_group_residual_result.argtypes = [P, P]
         L.nik_group_gather_best.argtypes = [P, P, P, P, P]
@@ -355,6 +358,10 @@ class CorrelationFlow:
 
     def set_streams(self, n):
         return self._L.nik_set_streams(self._ctx, int(n))
+
+    def set_chunk(self, pairs):
+        """batched calls are cut into chunks of at most `pairs` pairs (0: one chunk per stream); returns the previous value"""
+        return self._L.nik_set_chunk(self._ctx, int(pairs))
 
     # ---- camera undistortion (Camera::Camera maps / Camera::UndistortImage, camera.cc:45-47,92-93) ----
     def set_undistort(self, map1=None, map2=None):
@@ -571,6 +578,16 @@ class Group:
         b, e = C.c_int(), C.c_int()
         load().nik_group_shard(int(n), int(world), int(rank), C.byref(b), C.byref(e))
         return b.value, e.value
+
+    @staticmethod
+    def pick_best(records):
+        """records: [world][8] doubles (score, global index, pose x3, info x3) -> winning rank by the reference's rule (-1: none)"""
+        r = np.ascontiguousarray(records, np.float64).reshape(-1, 8)
+        return load().nik_group_pick_best(_p(r), int(r.shape[0]))
+
+    def comm_ranks(self):
+        """ranks the RCCL communicator spans (ncclCommCount); 0 = no RCCL in use"""
+        return self._L.nik_group_comm_ranks(self._g)
 
     def allreduce_residual(self, wait=True):
         out = np.zeros(4, np.float64)

@@ -38,9 +38,10 @@ def ang_diff(a, b):
 # MEASURED, not guessed (tests/test_gpu_wide.py::test_response_noise_bounds_the_tie_tolerance, profiles/r02_response_noise.json):
 # from identical float32 spectra the rotation response of the CPU float32 oracle deviates from the float64 evaluation by
 # up to 6.0e-4 of the peak and the HIP path by up to 5.8e-4 (EstimateTrans divides by Kzz + lambda, whose small bins carry
-# percent-level float32 error); two peaks closer than the sum of those deviations (1.2e-3) can legitimately swap.  That
-# test keeps this constant between 1x and 4x of the measured sum.
-ROT_TIE_REL = 1.5e-3
+# percent-level float32 error); two peaks closer than the sum of those deviations (1.2e-3) can legitimately swap.  The
+# constant IS that measured sum (the largest gap ever accepted in the 512 + 6144 + 2 x 3072 pair sweeps was 9.2e-4); the
+# test keeps it between 1x and 4x of what it measures.
+ROT_TIE_REL = 1.2e-3
 
 
 def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=None):

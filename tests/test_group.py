@@ -1,6 +1,6 @@
 """nik_group (multi-GPU C ABI): what a 1-GPU box can check.
 
-* nik_group_shard partitions like kcc_dist.shard_range (CPU).
+* nik_group_shard / nik_group_pick_best, the host rules of the group: tests/test_dist_gloo.py (CPU, two gloo ranks).
 * a local group of one GPU: sharded tracking / loop closure through the group equal the direct context calls bit for bit,
   and the device-reduced residual statistics equal the host sum over the per-pair results.
 * the same through RCCL itself (NIK_GROUP_FORCE_RCCL=1: ncclCommInitAll / ncclCommInitRank with one rank, all-reduce and
@@ -14,21 +14,7 @@ import numpy as np
 import pytest
 
 import synth
-from kcc_helpers import PKG, SMALL, load_module, nik
-
-kd = load_module("kcc_dist", os.path.join(PKG, "kcc_dist.py"))
-
-
-def test_group_shard_partitions_like_the_python_glue():
-    N = nik()
-    for n in (0, 1, 7, 32, 255, 256, 4096):
-        for world in (1, 2, 3, 8):
-            cover = []
-            for r in range(world):
-                b, e = N.Group.shard(n, world, r)
-                assert (b, e) == kd.shard_range(n, world, r)
-                cover += list(range(b, e))
-            assert cover == list(range(n))
+from kcc_helpers import SMALL, nik
 
 
 def _host_stats(res):
