@@ -190,6 +190,7 @@ int upload_table(nik_ctx* c, const std::vector<float2>& h, float2** d) {
 int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     f.g.rows = rows; f.g.cols = cols; f.g.hr = rows / 2 + 1;
     f.real_elems = (size_t)rows * cols; f.spec_elems = (size_t)f.g.hr * cols;
+    if (kfwd_parts(f.g, false) > KCC_MAXPARTS) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%d x %d: more running-max parts than KCC_MAXPARTS", rows, cols);
     const int h = rows / 2;
     const PlanDesc ph = plan_desc(h), pc = plan_desc(cols);
     int rc;
@@ -595,7 +596,8 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
     HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
     HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * (c->s_elems * c->max_batch + 16)));      // zero borders are never overwritten
     HIP_TRY(c, hipMalloc(&L.partials, sizeof(Partial) * c->partial_stride * c->max_items));
-    HIP_TRY(c, hipMalloc(&L.maxbuf, sizeof(unsigned) * 2 * c->max_items));
+    HIP_TRY(c, hipMalloc(&L.maxbuf, sizeof(unsigned) * 2 * KCC_MAXPARTS * c->max_items));
+    HIP_TRY(c, hipMemset(L.maxbuf, 0, sizeof(unsigned) * 2 * KCC_MAXPARTS * c->max_items));
     HIP_TRY(c, hipMalloc(&L.energy, sizeof(float) * 2 * c->max_items));
     HIP_TRY(c, hipMemset(L.energy, 0, sizeof(float) * 2 * c->max_items));
     HIP_TRY(c, hipMalloc(&L.rot_res, sizeof(SurfaceResult) * c->max_batch));
@@ -983,7 +985,7 @@ static int ensure_kzz_run(nik_ctx* c, Lane& L, const std::vector<nik_frame>& tod
               launch_A_inv_kernel_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, c->spec_max, kernel_fn(c), L.maxbuf, L.energy, 0, 1); }
             { Stage st(c, L, kname("kB", f.g.cols, "fwd_kzz").c_str(), m * 2 * Cb(f));
               launch_B_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, kz, f.spec_elems, didx(L, IX_KEY)); }
-            launch_store_mzz(L.stream, m, L.maxbuf, didx(L, IX_KEY), mz);
+            launch_store_mzz(L.stream, m, f.g, L.maxbuf, didx(L, IX_KEY), mz);
         }
         HIP_TRY(c, hipGetLastError());
         // publish as a slot write of lane 0 so that other lanes order their reads after it

@@ -16,12 +16,33 @@
 namespace kcc {
 
 __host__ __device__ constexpr bool is_base_radix(int r) { return r == 2 || r == 3 || r == 4 || r == 5 || r == 7 || r == 8; }
-__host__ __device__ constexpr int first_factor(int r) {
-    return is_base_radix(r) ? r : (r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : 7);
+__host__ __device__ constexpr int gcd_(int a, int b) { return b == 0 ? a : gcd_(b, a % b); }
+// Factor split R = A * B of a composite radix.  Coprime splits come first (largest base radix A with gcd(A, R/A) = 1): they
+// run as a Good-Thomas prime-factor transform with NO twiddle multiplications between the two stages (15 = 3 x 5,
+// 18 = 2 x 9, 20 = 4 x 5, 24 = 8 x 3, 10 = 2 x 5 ...; a radix-24 butterfly loses 21 of its complex multiplications, a
+// 480-point transform a fifth of its arithmetic).  Otherwise Cooley-Tukey with compile-time twiddles (16 = 4 x 4, 9 = 3 x 3).
+#ifndef KCC_PFA
+#define KCC_PFA 1
+#endif
+__host__ __device__ constexpr int pfa_factor(int r) {
+    if (!KCC_PFA) return 0;
+    const int cand[6] = { 8, 7, 5, 4, 3, 2 };
+    for (int i = 0; i < 6; ++i) if (r % cand[i] == 0 && r / cand[i] > 1 && gcd_(cand[i], r / cand[i]) == 1) return cand[i];
+    return 0;
 }
-// register index holding output k of dft_run<R>
+__host__ __device__ constexpr int first_factor(int r) {
+    return is_base_radix(r) ? r : pfa_factor(r) ? pfa_factor(r) : (r % 4 == 0 ? 4 : r % 2 == 0 ? 2 : r % 3 == 0 ? 3 : r % 5 == 0 ? 5 : 7);
+}
+__host__ __device__ constexpr bool is_pfa(int r) { return !is_base_radix(r) && pfa_factor(r) != 0; }
+// register index holding output k of dft_run<R>.  Cooley-Tukey (k = k1 + A k2): row k1 = k % A, column = the position of
+// k2 = k / A inside the B-point sub-transform.  Prime-factor (k = k1 mod A, k = k2 mod B): row k % A, column position of k % B.
 template <int R> __host__ __device__ constexpr int dft_pos(int k) {
-    return is_base_radix(R) ? k : (R / first_factor(R)) * (k % first_factor(R)) + k / first_factor(R);
+    if constexpr (is_base_radix(R)) {
+        return k;
+    } else {
+        constexpr int A = first_factor(R), B = R / A;
+        return B * (k % A) + dft_pos<B>(is_pfa(R) ? k % B : k / A);
+    }
 }
 
 // In-register DFT of R points (R = product of base radices).  Output k ends up in v[dft_pos<R>(k)].
@@ -29,6 +50,27 @@ template <int R, bool INV>
 __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
     if constexpr (is_base_radix(R)) {
         Radix<R, INV>::run(v);
+    } else if constexpr (is_pfa(R)) {
+        constexpr int A = first_factor(R), B = R / A;
+        // Good-Thomas: input n = (B n1 + A n2) mod R, output k with k = k1 (mod A), k = k2 (mod B):
+        //   W_R^(n k) = W_A^(n1 k1) W_B^(n2 k2) -- a plain A x B two-dimensional transform.  All index maps are compile-time
+        //   register renames.
+        float2 t[A][B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) {
+            float2 c[A];
+#pragma unroll
+            for (int n1 = 0; n1 < A; ++n1) c[n1] = v[(B * n1 + A * n2) % R];
+            dft_run<A, INV>(c);
+#pragma unroll
+            for (int k1 = 0; k1 < A; ++k1) t[k1][n2] = c[dft_pos<A>(k1)];
+        }
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) {
+            dft_run<B, INV>(t[k1]);                           // output k2 of row k1 sits at t[k1][dft_pos<B>(k2)]
+#pragma unroll
+            for (int i = 0; i < B; ++i) v[B * k1 + i] = t[k1][i];
+        }
     } else {
         constexpr int A = first_factor(R), B = R / A;
         // n = B*n1 + n2, k = k1 + A*k2:  DFT_A over n1, twiddle W_R^(n2*k1), DFT_B over n2
@@ -66,7 +108,7 @@ __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
             for (int n2 = 0; n2 < B; ++n2) u[n2] = v[B * k1 + n2];
             dft_run<B, INV>(u);
 #pragma unroll
-            for (int k2 = 0; k2 < B; ++k2) v[B * k1 + k2] = u[dft_pos<B>(k2)];
+            for (int k2 = 0; k2 < B; ++k2) v[B * k1 + k2] = u[k2];      // output k2 stays at u's position dft_pos<B>(k2)
         }
     }
 }

@@ -54,7 +54,7 @@ struct Tables {
 };
 
 // radices of the instantiated plan for length n (np = 0 if n is not instantiated)
-struct PlanDesc { int n, np, r[3]; };
+struct PlanDesc { int n, np, r[3], t; };      // t: threads per line
 PlanDesc plan_desc(int n);
 PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for half length n
 
@@ -139,6 +139,10 @@ void launch_A_inv_argmax(hipStream_t s, int n_items, PlaneGeom g, Tables t, cons
 void launch_A_inv_argmax_win(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
                              Partial* partials, int partial_stride, const int* win_row, const int* win_col, int radius, int mirror);
 int  argmax_blocks(PlaneGeom g);
+// running max of the kernel planes: kernel_fwd files one part per wave and column tile in maxbuf[item][plane][KCC_MAXPARTS]
+// (float bits); the ridge solve folds them.  kfwd_parts: parts per plane (half: the Hermitian-half zz plane)
+enum { KCC_MAXPARTS = 1024 };
+int  kfwd_parts(PlaneGeom g, bool half);
 
 // ---- B-type: contiguous spectrum lines along `cols` ----
 void launch_B_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
@@ -174,7 +178,7 @@ void launch_B_mul_inv_x(hipStream_t s, int n_items, PlaneGeom g, Tables t, bool 
 void launch_B_solve_cached(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                            size_t plane_stride, const unsigned* maxbuf, const float2* kzz, size_t kzz_stride,
                            const unsigned* mzz, const int* z_idx, float lambda, float2* out, size_t out_stride);
-void launch_store_mzz(hipStream_t s, int n, const unsigned* maxbuf, const int* slots, unsigned* mzz);
+void launch_store_mzz(hipStream_t s, int n, PlaneGeom g, const unsigned* maxbuf, const int* slots, unsigned* mzz);
 
 // half-spectrum energies for the gaussian kernel: energy[item] = {sum|X|^2, sum|Z|^2}
 void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, size_t x_stride, const int* x_idx,

@@ -36,15 +36,15 @@ bool fft_line_supported(int n_) {
     return false;
 }
 PlanDesc plan_desc_inv(int n_) {
-    PlanDesc d{ n_, 0, { 1, 1, 1 } };
-#define X(n) if (n_ == n) { using P = PlanInv<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; }
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
+#define X(n) if (n_ == n) { using P = PlanInv<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
     KCC_HALF_LIST(X)
 #undef X
     return d;
 }
 PlanDesc plan_desc(int n_) {
-    PlanDesc d{ n_, 0, { 1, 1, 1 } };
-#define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; }
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
+#define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
     KCC_HALF_LIST(X)
     KCC_LINE_LIST(X)
 #undef X
@@ -59,6 +59,9 @@ PlanDesc plan_desc(int n_) {
 #endif
 #ifndef KCC_ALX
 #define KCC_ALX 16
+#endif
+#ifndef KCC_WAVE_REGION
+#define KCC_WAVE_REGION 1
 #endif
 // Performance ablation (tuning builds only: -DKCC_ABLATE, tools/ablate.sh; results become garbage).  $NIK_ABLATE bits:
 // 1 no loads / gathers, 2 no stores, 4 no FFT, 8 exit at once (dispatch cost only), 16 no gather staging, 32 no gather sampling,
@@ -352,7 +355,7 @@ struct AArgs {
     float* real_out; size_t real_stride;
     Partial* partials; int partial_stride;
     const int* win_row; const int* win_col; int win_radius, win_mirror;   // ARGMAX_WIN: per-item window centre; mirror: also centre + rows/2
-    KernelFn fn; unsigned* maxbuf; const float* energy;
+    KernelFn fn; unsigned* maxbuf; const float* energy;      // maxbuf: per-wave running-max parts [item][2][KCC_MAXPARTS] (float bits)
 };
 
 // most waves per SIMD ever asked of the register allocator: the 360-point kernels need ~100 VGPRs (a 96-register cap spilled)
@@ -370,12 +373,25 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
     static constexpr int NPITCH = HH + 1;                // natural-order pitch: odd -> conflict-free transposes
     static constexpr int LDS_ELEMS = LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
     static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
+    // Wave-owned LDS regions (wave-local plans, T | 64): wave w holds lines [w LPW, (w+1) LPW).  Their natural-order rows
+    // occupy [w LPW NPITCH, (w+1) LPW NPITCH); their exchange buffers are placed INSIDE that range (pitch EPITCH <= NPITCH
+    // from the region's start), so between the workgroup-wide load and the workgroup-wide store a wave only ever touches LDS
+    // that no other wave touches: the natural -> exchange -> natural hand-overs need a wave-level fence, not an s_barrier,
+    // and the waves of a workgroup drift apart instead of marching in lock-step (2 barriers per tile instead of 5 to 7).
+    static constexpr int LPW = (64 % T == 0) ? 64 / T : 0;
+    static constexpr bool WREG = KCC_WAVE_REGION && KCC_WAVE_LOCAL && LPW > 0 && (LX % (LPW > 0 ? LPW : 1) == 0) && EPITCH <= NPITCH;
+    __device__ static __forceinline__ float2* ex_of(float2* lds, int line) {
+        if constexpr (WREG) return lds + (line / LPW) * (LPW * NPITCH) + (line % LPW) * EPITCH;
+        else return lds + line * EPITCH;
+    }
     // waves per SIMD the LDS footprint allows: ask the register allocator to fit that occupancy
     static constexpr int BLOCKS = (int)(160 * 1024 / BYTES) > 8 ? 8 : (int)(160 * 1024 / BYTES);
     static constexpr int WPS_ = (BLOCKS * ((NT + 63) / 64) + 3) / 4;
     static constexpr int WPS = WPS_ > KCC_WPS_MAX(HH) ? KCC_WPS_MAX(HH) : (WPS_ < 1 ? 1 : WPS_);
 };
 
+// hand-over between a wave's own natural-order rows and its own exchange buffers (ACfg::WREG), else a workgroup barrier
+template <bool WREG> __device__ __forceinline__ void region_sync() { line_sync<WREG>(); }
 template <int RR>
 __device__ __forceinline__ void zero_fill(float2 (&v)[RR]) {
 #pragma unroll
@@ -770,9 +786,9 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #pragma unroll
         for (int q = 0; q < D::RF; ++q) o[j + q * D::MF] = vin[0][q];
     }
-    float2* const ex[1] = { lds + line * C::EPITCH };
+    float2* const ex[1] = { C::ex_of(lds, line) };
     if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
-    __syncthreads();                                         // exchange buffer fully consumed
+    region_sync<C::WREG>();                                  // exchange buffer fully consumed
     if (j < D::ML) {
 #pragma unroll
         for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
@@ -851,9 +867,9 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
             }
         }
         __syncthreads();                                     // staged rows consumed before the exchange overwrites them
-        float2* const ex[1] = { lds + line * C::EPITCH };
+        float2* const ex[1] = { C::ex_of(lds, line) };
         if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, tw_f);
-        __syncthreads();                                     // exchange buffer fully consumed
+        region_sync<C::WREG>();                              // exchange buffer fully consumed
         if (j < D::ML) {
 #pragma unroll
             for (int q = 0; q < D::RL; ++q) lds[line * C::NPITCH + j + q * D::ML] = vout[0][q];
@@ -919,8 +935,8 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
 #pragma unroll
         for (int q = 0; q < DI::RF; ++q) vin[0][q] = lds[line * C::NPITCH + j + q * DI::MF];
     }
-    __syncthreads();                                         // natural buffer consumed before the exchange overwrites it
-    float2* const ex[1] = { lds + line * C::EPITCH };
+    region_sync<C::WREG>();                                  // natural buffer consumed before the exchange overwrites it
+    float2* const ex[1] = { C::ex_of(lds, line) };
     if (!ABL(a, 4)) fft_chain<P, true, 1, WL>(vin, vout, j, ex, a.tw_i);
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
@@ -984,16 +1000,13 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
             }
         }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-        if ((tid & 63) == 0) red_f[tid >> 6] = mx;
-        __syncthreads();                                     // also: exchange buffer consumed before the forward chain
-        if (tid == 0) {
-            float m2 = red_f[0];
-            for (int w = 1; w < NW; ++w) m2 = fmaxf(m2, red_f[w]);
-            atomicMax(a.maxbuf + 2 * item + plane, __float_as_uint(m2));   // non-negative floats order as uints
-        }
+        // max|k| of the plane (k /= max, correlation_flow.cc:214): every wave files the max of its own lines as one part --
+        // a plain store, no atomic and no workgroup rendezvous; the ridge solve folds the parts (parts_max)
+        if ((tid & 63) == 0) a.maxbuf[(size_t)(2 * item + plane) * KCC_MAXPARTS + bx * NW + (tid >> 6)] = __float_as_uint(mx);
+        region_sync<C::WREG>();                              // exchange buffer consumed before the forward chain
         float2 fout[1][DF::RL];
         if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vout, fout, j, ex, a.tw_f);
-        __syncthreads();
+        region_sync<C::WREG>();
         if (j < DF::ML) {
 #pragma unroll
             for (int q = 0; q < DF::RL; ++q) lds[line * C::NPITCH + j + q * DF::ML] = fout[0][q];
@@ -1072,6 +1085,13 @@ int zz_half_columns(PlaneGeom g) { const int lx = inv_lx_for(g.rows / 2, g.cols,
 // when only its columns |c| <= need are consumed (the polar gather never leaves the inscribed circle)
 int shifted_columns(PlaneGeom g, int need) { const int lx = inv_lx_for(g.rows / 2, g.cols, EPI_SHIFTED); return std::min(g.cols, (std::min(g.cols / 2, need) / lx + 1) * lx); }
 int argmax_blocks(PlaneGeom g) { return g.cols / inv_lx_for(g.rows / 2, g.cols, EPI_ARGMAX); }
+// running-max parts kernel_fwd files per kernel plane: one per wave and column tile (half: the Hermitian-half zz plane)
+int kfwd_parts(PlaneGeom g, bool half) {
+    const int hh = g.rows / 2, lx = inv_lx_for(hh, g.cols, EPI_KFWD_POLY3);
+    const int threads = lx * plan_desc_inv(hh).t, nw = (threads + 63) / 64;
+    const int tiles = half ? (g.cols / 2) / lx + 1 : g.cols / lx;
+    return tiles * nw;
+}
 
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a, size_t min_lds = 0) {
     a.n_items = n_items;
@@ -1258,7 +1278,7 @@ struct BArgs {
     float2* dst; size_t dst_stride; const int* dst_slot;          // primary output
     float2* dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
-    const unsigned* maxbuf; float lambda;
+    const unsigned* maxbuf; int n_parts[2]; float lambda;     // running-max parts of the kernel planes (see kA_inv kernel_fwd)
     int zz_half;                                                  // SOLVE_INV: plane 0 holds only the columns <= N/2 (Hermitian);
                                                                   // (FWD_)MUL_INV: > 0 = number of zz-plane columns to store
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
@@ -1321,12 +1341,21 @@ __device__ __forceinline__ void store_strided(const float2 (&v)[RR], float2* __r
     for (int q = 0; q < RR; ++q) p[q * stride] = v[q];
 }
 
+// max over the running-max parts of one kernel plane; called by the (full) first wave of a workgroup, result in every lane
+__device__ __forceinline__ float parts_max(const unsigned* __restrict__ p, int n, int lane) {
+    unsigned m = 0u;                                         // non-negative floats order as their bit patterns
+    for (int i = lane; i < n; i += 64) m = max(m, p[i]);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    return __uint_as_float(m);
+}
+
 template <int N, int MODE>
 __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = BCfg<N, MODE>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
     static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
     float2* lds = reinterpret_cast<float2*>(smem);
+    __shared__ float s_rmax[2];
     if (ABL(a, 8)) return;
     const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
     const int item = a.rev ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y, k = blockIdx.x * C::LK + (int)lk;      // spectrum line (row index of the half spectrum)
@@ -1370,7 +1399,6 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
         // xzf = xf * zf.conjugate() for (z,z) and (x,z)   (correlation_flow.cc:210-211,220-221)
         float2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
-        if (blockIdx.x == 0 && tid < 2) a.maxbuf_zero[2 * item + tid] = 0u;    // consumed by the following kernel_fwd launch
         // the key spectrum line is needed only after the forward chain: issue its loads first (latency hidden)
         load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
         if (MODE == B_FWD_MUL_INV) {
@@ -1415,7 +1443,6 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     } else if (MODE == B_ZZ_INV) {
         // Kzz half of the kernel stage: |Z|^2 -> inverse col FFT (plane 0)
         float2 zv[1][DI::RF], o[1][DI::RL];
-        if (blockIdx.x == 0 && tid < 1) a.maxbuf_zero[2 * item] = 0u;
         load_strided(zv[0], a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
 #pragma unroll
         for (int q = 0; q < DI::RF; ++q) zv[0][q] = make_float2(zv[0][q].x * zv[0][q].x + zv[0][q].y * zv[0][q].y, 0.f);
@@ -1424,7 +1451,6 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     } else if (MODE == B_MUL_INV_X || MODE == B_FWD_MUL_INV_X) {
         // Kxz half: X conj Z -> inverse col FFT (plane 1)
         float2 pr[1][DI::RF], o[1][DI::RL], zv[DI::RF];
-        if (blockIdx.x == 0 && tid < 1) a.maxbuf_zero[2 * item + 1] = 0u;
         load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
         if (MODE == B_FWD_MUL_INV_X) {
             float2 vin[1][DF::RF], x[1][DF::RL];
@@ -1449,9 +1475,11 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         const int zslot = a.z_idx[item];
         load_strided(vin[0], a.src + (size_t)item * a.src_stride + a.in_plane_stride + loff, DF::MF, valid && j < DF::MF);
         load_strided(kz, a.kzz + (size_t)zslot * a.kzz_stride + loff, DF::ML, valid && j < DF::ML);
-        const float rzz = 1.0f / __uint_as_float(a.mzz[zslot]);
-        const float rxz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 1]);
+        static_assert(C::NT >= 64, "parts_max needs one full wave");
+        if (tid < 64) { const float m = parts_max(a.maxbuf + (size_t)(2 * item + 1) * KCC_MAXPARTS, a.n_parts[1], (int)tid); if (tid == 0) s_rmax[1] = m; }
         if (!nofft) fft_chain<P, false, 1>(vin, kx, j, ex1, a.tw_f);
+        const float rzz = 1.0f / __uint_as_float(a.mzz[zslot]);      // (s_rmax: written before the barriers inside the chain)
+        const float rxz = 1.0f / s_rmax[1];
         static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
@@ -1487,8 +1515,12 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             load_strided(vin[0], src, DF::MF, valid && j < DF::MF);
         }
         load_strided(vin[1], src + a.in_plane_stride, DF::MF, valid && j < DF::MF);
-        const float rzz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 0]);
-        const float rxz = 1.0f / __uint_as_float(a.maxbuf[2 * item + 1]);
+        static_assert(C::NT >= 64, "parts_max needs one full wave");
+        if (tid < 64) {
+            const float m0 = parts_max(a.maxbuf + (size_t)(2 * item + 0) * KCC_MAXPARTS, a.n_parts[0], (int)tid);
+            const float m1 = parts_max(a.maxbuf + (size_t)(2 * item + 1) * KCC_MAXPARTS, a.n_parts[1], (int)tid);
+            if (tid == 0) { s_rmax[0] = m0; s_rmax[1] = m1; }
+        }
         if (!nofft) {
             if (C::SEQ) {
                 float2 (&v0)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[0]); float2 (&v1)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[1]);
@@ -1500,6 +1532,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
                 fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
             }
         }
+        const float rzz = 1.0f / s_rmax[0], rxz = 1.0f / s_rmax[1];   // (wave 0 wrote them before the barriers inside the chains)
         // ML is even for every plan, so (-1)^l is the same for all q: one sign per thread
         static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
@@ -1630,22 +1663,25 @@ void launch_B_solve_cached(hipStream_t s, int n_items, PlaneGeom g, Tables t, co
                            const unsigned* mzz, const int* z_idx, float lambda, float2* out, size_t out_stride) {
     BArgs a = base_bargs(g, t);
     a.src = buf; a.src_stride = item_stride; a.in_plane_stride = plane_stride; a.maxbuf = maxbuf; a.lambda = lambda;
+    a.n_parts[0] = 0; a.n_parts[1] = kfwd_parts(g, false);
     a.kzz = kzz; a.kzz_stride = kzz_stride; a.mzz = mzz; a.z_idx = z_idx; a.dst = out; a.dst_stride = out_stride;
 #define CALL(N) launchB_t<N, B_SOLVE_CACHED>(s, n_items, a)
     DISPATCH_LINE(g.cols, CALL)
 #undef CALL
 }
-__global__ void k_store_mzz(int n, const unsigned* __restrict__ maxbuf, const int* __restrict__ slots, unsigned* __restrict__ mzz) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) mzz[slots[i]] = maxbuf[2 * i];
+__global__ __launch_bounds__(64) void k_store_mzz(const unsigned* __restrict__ maxbuf, int n_parts, const int* __restrict__ slots, unsigned* __restrict__ mzz) {
+    const int i = blockIdx.x;
+    const float m = parts_max(maxbuf + (size_t)(2 * i) * KCC_MAXPARTS, n_parts, threadIdx.x);
+    if (threadIdx.x == 0) mzz[slots[i]] = __float_as_uint(m);
 }
-void launch_store_mzz(hipStream_t s, int n, const unsigned* maxbuf, const int* slots, unsigned* mzz) {
-    hipLaunchKernelGGL(k_store_mzz, dim3((n + 63) / 64), dim3(64), 0, s, n, maxbuf, slots, mzz);
+void launch_store_mzz(hipStream_t s, int n, PlaneGeom g, const unsigned* maxbuf, const int* slots, unsigned* mzz) {
+    hipLaunchKernelGGL(k_store_mzz, dim3(n), dim3(64), 0, s, maxbuf, kfwd_parts(g, false), slots, mzz);
 }
 void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* buf, size_t item_stride,
                         size_t plane_stride, const unsigned* maxbuf, float lambda, float2* out, size_t out_stride, bool zz_half) {
     BArgs a = base_bargs(g, t);
     a.src = buf; a.src_stride = item_stride; a.in_plane_stride = plane_stride; a.maxbuf = maxbuf; a.lambda = lambda;
+    a.n_parts[0] = kfwd_parts(g, zz_half); a.n_parts[1] = kfwd_parts(g, false);
     a.dst = out; a.dst_stride = out_stride; a.zz_half = zz_half ? 1 : 0;
 #define CALL(N) launchB_t<N, B_SOLVE_INV>(s, n_items, a)
     DISPATCH_LINE(g.cols, CALL)

@@ -11,11 +11,13 @@ table bug shows up here, bit for bit, before any GPU run:
 """
 from fractions import Fraction as F
 
+import os
+
 import numpy as np
 import pytest
 
 import synth
-from kcc_helpers import FULL, SMALL, nik
+from kcc_helpers import FULL, ROOT, SMALL, nik
 from oracle import kcc_oracle as ko
 
 GEOMS = [pytest.param(SMALL, id="60x80"), pytest.param(FULL, id="480x640")]
@@ -206,3 +208,16 @@ def test_exchange_swizzles_are_conflict_free_permutations():
         assert worst(lambda lk, j, q=q: lk * EP + 15 * j + q, lambda j: j < 16, NT, T, 16) == 1
     for q in range(16):
         assert worst(lambda lk, j, q=q: lk * EP + j + 15 * q, lambda j: j < 15, NT, T, 32) <= 2
+
+
+def test_fft_butterflies_on_the_host(tmp_path):
+    """The in-register butterflies of the FFT engine (kcc_fft2.h dft_run: Good-Thomas prime-factor and Cooley-Tukey splits over
+    the base radices of kcc_fft.h) compiled for the HOST (g++, tests/cpp/hipstub) and compared with a direct float64 DFT, both
+    directions, every radix any plan uses; dft_pos must be a permutation."""
+    import subprocess
+    exe = os.path.join(str(tmp_path), "dft_host_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "tests", "cpp", "hipstub"),
+                           "-I" + os.path.join(ROOT, "ni-slam_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "dft_host_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert "pfa=1" in out.stdout and "pfa=0" in out.stdout
