@@ -18,6 +18,7 @@ import argparse
 import glob
 import json
 import os
+import shutil
 import sys
 import time
 
@@ -70,26 +71,71 @@ def _profile(cf, run_once, steps):
     return kernels
 
 
-def _roofline(kernels, batch):
-    """the kernel with the largest share of GPU time against the HBM roofline.  `achieved` uses the ALGORITHMIC bytes of the
-    launch; `traffic` is that kernel's MEASURED HBM bytes per launch from the committed rocprofv3 --pmc summary
-    (not re-measured in this run: traffic_source names the file) and frac_moved_bytes prices the kernel on those bytes."""
+def _live_rocprof(args, workload, batch):
+    """rocprofv3 passes over a short run of this very bench (one stream, no nested profiling): per-kernel durations from
+    --kernel-trace --stats and HBM bytes from the FETCH_SIZE / WRITE_SIZE passes.  Any failure returns None (the line then
+    falls back on the committed profiles/ summary and says so)."""
+    if args.no_live_prof or shutil.which("rocprofv3") is None:
+        return None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import rocprof_summary
+        out = os.path.join(ROOT, "gpurun_out", "bench_live_prof")
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "4", "--warmup", "1",
+               "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof"]
+        r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=180)
+        return r if r["stats"] else None
+    except Exception as e:                                    # noqa: BLE001
+        sys.stderr.write("live rocprof pass failed: %s\n" % str(e)[:300])
+        return None
+
+
+def _roofline(kernels, batch, live=None):
+    """The kernel with the largest share of GPU time against the HBM roofline.
+    achieved = ALGORITHMIC bytes of a launch / its average duration.  The duration is measured twice: HIP events
+    on the launch stream inside this process (avg_ms_hip_event) and rocprofv3 --kernel-trace --stats (avg_ms_rocprof: a live
+    pass of this run when rocprofv3 is present, else the committed profiles/<tag>_kernel_times.json).  frac is priced on the
+    LARGER of the two, and the line says whether they agree within 5 %.
+    traffic = the kernel's measured HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes (live, else the committed
+    summary -- traffic_source says which); frac_moved_bytes prices the kernel on those bytes."""
     if not kernels:
         return None
     top = kernels[0]
-    ach = top["bytes_per_launch"] / (top["avg_ms"] * 1e-3) / 1e9
-    traffic, src = None, None
+    name = top["name"]
+    t_hip = top["avg_ms"]
+    t_roc, roc_src, traffic, tr_src = None, None, None, None
+    if live is not None:
+        if name in live["stats"]:
+            t_roc, roc_src = live["stats"][name]["avg_ms"], "live rocprofv3 --kernel-trace --stats pass of this run"
+        if name in live["traffic"]:
+            traffic, tr_src = live["traffic"][name], "live rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run"
     try:
-        f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
-        pm = json.load(open(f))
-        if pm.get("pairs_per_launch") == batch:
-            traffic, src = pm["traffic_bytes_per_launch"].get(top["name"]), "profiles/" + os.path.basename(f)
-    except Exception:
+        if t_roc is None:
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_times.json")))[-1]
+            kt = json.load(open(f))
+            if kt.get("pairs_per_launch") == batch and name in kt["kernels"]:
+                t_roc, roc_src = kt["kernels"][name]["avg_ms"], "profiles/" + os.path.basename(f)
+        if traffic is None:
+            f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+            pm = json.load(open(f))
+            if pm.get("pairs_per_launch") == batch:
+                traffic, tr_src = pm["traffic_bytes_per_launch"].get(name), "profiles/" + os.path.basename(f) + " (committed, not re-measured)"
+    except Exception:                                         # noqa: BLE001
         pass
-    r = dict(bound="hbm", kernel=top["name"], achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4),
-             traffic=traffic, traffic_source=src, avg_ms=top["avg_ms"], bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
+    t_use = max(t_hip, t_roc) if t_roc else t_hip
+    ach = top["bytes_per_launch"] / (t_use * 1e-3) / 1e9
+    r = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4),
+             traffic=traffic, traffic_source=tr_src, avg_ms=round(t_use, 4), avg_ms_hip_event=t_hip,
+             avg_ms_rocprof=None if t_roc is None else round(t_roc, 4), rocprof_source=roc_src,
+             bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
+    if t_roc:
+        r["hip_event_over_rocprof"] = round(t_hip / t_roc, 4)
+        r["durations_agree_within_5pct"] = bool(abs(t_hip / t_roc - 1.0) <= 0.05)
+        if not r["durations_agree_within_5pct"]:
+            sys.stderr.write("WARNING: %s: HIP-event %.4f ms vs rocprof %.4f ms per launch disagree by more than 5 %%; roofline.frac uses the larger\n"
+                             % (name, t_hip, t_roc))
     if traffic:
-        r["frac_moved_bytes"] = round(traffic / (top["avg_ms"] * 1e-3) / HBM_PEAK, 4)
+        r["frac_moved_bytes"] = round(traffic / (t_use * 1e-3) / HBM_PEAK, 4)
     return r
 
 
@@ -105,32 +151,51 @@ def _line(metric, unit, value, world, args, ms_per_step, workload, bytes_per_uni
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank):
+def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank, hd=False):
+    """The headline workload (hd=False: 640x480 gray pairs) and configs[3] (hd=True: 1280x720 RGB frames -> integer luma ->
+    the same pair unit) share this code: one process per GPU, the pairs of a step sharded over the ranks, the residual
+    statistics reduced on every device and all-reduced through nik_group (RCCL inside the C ABI)."""
     from kcc_helpers import check_pose_parity, imposed_rerun
-    H, W, PD, PC = 480, 640, 720, 480
+    H, W, PD, PC = (720, 1280, 720, 480) if hd else (480, 640, 720, 480)
     B = args.batch
+    if hd and not args.batch_given:
+        B = 128 if world == 1 else 32            # configs[3]: "batch 256 frame-pairs sharded across 8 GPUs" = 32 per GPU
     U = B if args.unique <= 0 else min(args.unique, B)
+    if hd and args.unique <= 0:
+        U = min(B, 32)                           # (a 1280x720 canvas takes seconds to synthesise)
     gb = int(os.environ.get("NIK_BENCH_GLOBAL_BATCH", "0"))
+    mk = dict(max_theta=8.0, max_shift=60, ncanvas=8) if hd else dict(max_theta=10.0)
     if gb:      # test hook: ONE global batch, this rank takes its contiguous shard (sharded == unsharded can then be checked)
-        gk, gc_, _ = synth.make_unique_batch(gb, H, W, seed0=777, max_theta=10.0)
+        gk, gc_, _ = synth.make_unique_batch(gb, H, W, seed0=777, **mk)
         b0, e0 = N.Group.shard(gb, world, rank)
         keys_u8, curs_u8, B = gk[b0:e0], gc_[b0:e0], e0 - b0
         U = B
     else:
-        keys_u8, curs_u8, motions = synth.make_unique_batch(U, H, W, seed0=1000 * (rank + 1), max_theta=10.0)
+        keys_u8, curs_u8, motions = synth.make_unique_batch(U, H, W, seed0=1000 * (rank + 1), **mk)
     reps = (B + U - 1) // U
-    d_keys = torch.from_numpy(np.tile(keys_u8, (reps, 1, 1))[:B]).to(dev)
-    d_curs = torch.from_numpy(np.tile(curs_u8, (reps, 1, 1))[:B]).to(dev)
-    torch.cuda.synchronize()
     cfg = N.default_config()
     cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
     key_slots, cur_slots = list(range(B)), list(range(B, 2 * B))
+    d_rgb = None
+    if hd:
+        # frames arrive as RGB (R = G = B = the synthetic texture, so the integer luma returns it exactly and the oracle can
+        # be fed the gray images); the colour conversion of the current frames is part of every step
+        to_rgb = lambda a: torch.from_numpy(np.repeat(np.tile(a, (reps, 1, 1))[:B, :, :, None], 3, axis=3).copy()).to(dev)   # noqa: E731
+        d_keys_rgb, d_rgb = to_rgb(keys_u8), to_rgb(curs_u8)
+        d_keys = torch.empty((B, H, W), dtype=torch.uint8, device=dev); d_curs = torch.empty_like(d_keys)
+        torch.cuda.synchronize()
+        cf.rgb_to_gray_dev(d_keys_rgb.data_ptr(), B, d_keys.data_ptr())
+        del d_keys_rgb
+    else:
+        d_keys = torch.from_numpy(np.tile(keys_u8, (reps, 1, 1))[:B]).to(dev)
+        d_curs = torch.from_numpy(np.tile(curs_u8, (reps, 1, 1))[:B]).to(dev)
+    torch.cuda.synchronize()
     cf.intermedium_batch_dev(d_keys.data_ptr(), B, key_slots)       # keyframe spectra: prepared before the timed region
     cf.synchronize()
 
     # the residual all-reduce: through the library's nik_group (RCCL inside the C ABI).  Test hook NIK_BENCH_BACKEND=gloo
     # (several ranks on one device, where RCCL cannot form a communicator): device-side reduction + torch.distributed.
-    comm, grp, stats_t = "nik_group (single GPU: no collective)", None, None
+    comm, grp, stats_t, fallback = "nik_group (single GPU: no collective)", None, None, False
     if world > 1 and os.environ.get("NIK_BENCH_BACKEND", "nccl") != "nccl":
         cf.set_residual_stats(True)
         stats_t = torch.zeros(4, dtype=torch.float64)
@@ -145,7 +210,7 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
                 comm = "nik_group: RCCL all-reduce of 4 doubles per step inside the C ABI"
             grp = N.Group.rank(cf, rank, world, uid)
         except Exception as e:                                   # keep the measurement alive; say so in the line
-            grp = None
+            grp, fallback = None, True
             cf.set_residual_stats(True)
             stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
             comm = "FALLBACK torch.distributed all-reduce (nik_group failed: %s)" % str(e)[:200]
@@ -155,8 +220,12 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
     ring = [(N.NikPoseResult * B)() for _ in range(3)]
     state = {"k": 0}
 
+    rccl_ranks = grp.comm_ranks() if grp is not None else 0       # ncclCommCount of the library's communicator (0: none in use)
+
     def step():
         k = state["k"]
+        if d_rgb is not None:
+            cf.rgb_to_gray_async(d_rgb.data_ptr(), B, d_curs.data_ptr())
         res = cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=False, res=ring[k % 3])
         if grp is not None:
             grp.allreduce_residual(wait=False)                   # device-side reduction + RCCL, asynchronous
@@ -181,8 +250,13 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
         dist.barrier()
     dt = time.perf_counter() - t0
     stats = grp.residual_result() if grp is not None else (stats_t.cpu().numpy() if stats_t is not None else None)
+    rank_rates = [B / (dt / args.steps)]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_rates = [B / (float(x.item()) / args.steps) for x in allt]          # every rank's own pairs/s over its own clock
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = 1e3 * dt / args.steps
@@ -217,7 +291,7 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
             from oracle import kcc_oracle as ko
             ocfg = ko.default_config()
             ncores = os.cpu_count() or 1
-            ns = min(args.cpu_sample, U)
+            ns = min(args.cpu_sample, U, 16 if hd else U)
             # the oracle allocates plane-sized temporaries per call (like the reference's Eigen temporaries); on the 2x64-core
             # host its throughput peaks near 32 threads (tools/cpu_scale.py), so that is what is reported
             nthr = min(ncores, ns, 32)
@@ -233,11 +307,17 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
                        host_cpus=ncores, gpu_results_match=bool(parity_ok), pairs_compared=ns)
         bpp = algorithmic_bytes(H, W, PD, PC)
         bpc = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
-        out = _line("frame-pairs/s (corr-volume + pose solve) at 640x480", "frame-pairs/s", pairs_per_s, world, args, ms_per_step,
-                    "configs[1]: 640x480 mono, ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), polynomial kernel, polar 720x480, Kzz not cached",
+        live = _live_rocprof(args, "hd" if hd else "pairs", B) if (world == 1 and kernels) else None
+        metric = "frame-pairs/s at 1280x720 RGB (configs[3])" if hd else "frame-pairs/s (corr-volume + pose solve) at 640x480"
+        wl = ("configs[3]: 1280x720 RGB -> integer luma -> ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), %d pairs per GPU per step, pairs sharded over the GPUs, RCCL residual all-reduce"
+              % B) if hd else "configs[1]: 640x480 mono, ComputeIntermedium(cur)+ComputePose(key,cur,small-rot), polynomial kernel, polar 720x480, Kzz not cached"
+        out = _line(metric, "frame-pairs/s", pairs_per_s, world, args, ms_per_step, wl,
                     bpp, dict(pairs_per_gpu_per_step=B, unique_pairs=U, parallelism="pairs sharded x%d" % world, residual_allreduce=comm),
-                    roofline=_roofline(kernels, B), cpu_baseline=cpu, parity_spot_check=parity_ok,
+                    roofline=_roofline(kernels, B, live), cpu_baseline=cpu, parity_spot_check=parity_ok,
                     residual_stats=None if stats is None else [float(v) for v in stats],
+                    multi_gpu=dict(world=world, rccl_ranks=rccl_ranks, fallback=bool(fallback),
+                                   pairs_per_s_per_rank_min=round(min(rank_rates), 1), pairs_per_s_per_rank_max=round(max(rank_rates), 1),
+                                   note="rccl_ranks = ncclCommCount of the library's communicator (0: one GPU, no collective); fallback: the residual all-reduce ran through torch.distributed instead of nik_group"),
                     kzz_cached_mode=None if pairs_per_s_cached is None else {
                         "value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": bpc,
                         "frac_of_8TBps": round(pairs_per_s_cached * bpc / HBM_PEAK, 4),
@@ -347,48 +427,6 @@ def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
     return out
 
 
-def workload_hd(args, N, torch, np, synth, dev, local_rank):
-    H, W, PD, PC = 720, 1280, 720, 480
-    B = min(args.batch, 128)
-    cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=B, max_frames=2 * B, device=local_rank)
-    U = min(B, 16)
-    keys, curs, _ = synth.make_unique_batch(U, H, W, seed0=11, max_theta=8.0, max_shift=60, ncanvas=8)
-    rep = (B + U - 1) // U
-    dk = torch.from_numpy(np.repeat(np.tile(keys, (rep, 1, 1))[:B, :, :, None], 3, axis=3).copy()).to(dev)
-    dc = torch.from_numpy(np.repeat(np.tile(curs, (rep, 1, 1))[:B, :, :, None], 3, axis=3).copy()).to(dev)
-    gk = torch.empty((B, H, W), dtype=torch.uint8, device=dev); gc = torch.empty_like(gk)
-    torch.cuda.synchronize()
-    cf.rgb_to_gray_dev(dk.data_ptr(), B, gk.data_ptr())
-    cf.intermedium_batch_dev(gk.data_ptr(), B, list(range(B))); cf.synchronize()
-    ring = [(N.NikPoseResult * B)() for _ in range(3)]
-
-    def step(k):
-        cf.rgb_to_gray_dev(dc.data_ptr(), B, gc.data_ptr())          # colour conversion is part of the step
-        return cf.track_batch_dev(gc.data_ptr(), list(range(B)), list(range(B, 2 * B)), True, sync=False, res=ring[k % 3])
-    for k in range(args.warmup):
-        step(k)
-    cf.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        res = step(k)
-    cf.synchronize(); torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    parity = None
-    if args.cpu_sample > 0:
-        from kcc_helpers import check_pose_parity
-        from oracle import kcc_oracle as ko
-        ns = min(4, U)
-        poses, infos, dbgs, _ = ko.track_pairs(ko.default_config(), keys[:ns], curs[:ns], True, nthreads=ns)
-        parity = all(check_pose_parity(res[i].as_dict(), poses[i], infos[i], dbgs[i], PD)[0] for i in range(ns))
-    kernels = [] if args.no_profile else _profile(cf, lambda: cf.track_batch_dev(gc.data_ptr(), list(range(B)), list(range(B, 2 * B)), True, sync=True), 3)
-    out = _line("frame-pairs/s at 1280x720 RGB (configs[3] geometry, one GPU)", "frame-pairs/s", B / dt, 1, args, 1e3 * dt,
-                "configs[3] on one GPU: 1280x720 RGB -> integer luma -> ComputeIntermedium + ComputePose, %d pairs per step (its 8-GPU shard runs the pairs workload's multi-rank code path)" % B,
-                algorithmic_bytes(H, W, PD, PC), dict(pairs_per_step=B, unique_pairs=U), parity_spot_check=parity,
-                roofline=_roofline(kernels, -1), cpu_baseline=None, kernels=kernels)
-    cf.close()
-    return out
-
-
 def workload_loop(args, N, torch, np, synth, dev, local_rank):
     H, W, PD, PC = 480, 640, 720, 480
     NC, MB = args.candidates, 128
@@ -454,7 +492,9 @@ def main():
     ap.add_argument("--candidates", type=int, default=4096, help="loop4096 workload: resident key frames")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")
+    ap.add_argument("--no-live-prof", action="store_true", help="skip the live rocprofv3 passes (durations + HBM bytes of the dominant kernel)")
     args = ap.parse_args()
+    args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
 
     import numpy as np
     import torch
@@ -480,16 +520,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    if args.workload == "pairs":
-        out = workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank)
+    if args.workload in ("pairs", "hd"):
+        out = workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank, hd=args.workload == "hd")
     elif world > 1:
         raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
     elif args.workload == "sequence":
         out = workload_sequence(args, N, torch, np, synth, dev, local_rank)
     elif args.workload == "pyramid":
         out = workload_pyramid(args, N, torch, np, synth, dev, local_rank)
-    elif args.workload == "hd":
-        out = workload_hd(args, N, torch, np, synth, dev, local_rank)
     else:
         out = workload_loop(args, N, torch, np, synth, dev, local_rank)
     if rank == 0 and out is not None:

@@ -174,6 +174,9 @@ int nik_match_topk(nik_ctx* ctx, nik_frame query, int n, const nik_frame* cands,
 /* Extension (config 4): interleaved 8-bit RGB (bgr=0) or BGR (bgr=1) images in HBM -> 8-bit gray with OpenCV's
  * integer luma weights (R*4899 + G*9617 + B*1868 + 8192) >> 14; n images of H x W.  The reference loads gray. */
 int nik_rgb_to_gray_dev(nik_ctx* ctx, int n, const uint8_t* d_rgb, int bgr, uint8_t* d_gray);
+/* the same without returning to the host: ordered on the device before every call enqueued later (and after everything
+ * enqueued before); results are ready when those later calls are */
+int  nik_rgb_to_gray_async(nik_ctx* ctx, int n, const uint8_t* d_rgb, int bgr, uint8_t* d_gray);
 
 /* ---- sequence driver: the tracking subset of MapBuilder ---------------- */
 

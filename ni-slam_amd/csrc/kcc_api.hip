@@ -424,9 +424,16 @@ struct Stage {
     }
     ~Stage() { set_launch_reverse(0); if (rec >= 0) (void)hipEventRecord(c->prof_recs[rec].b, s); }
 };
-std::string kname(const char* base, int len, const char* mode) {
-    char b[64]; snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode); return b;
+std::string kname(const char* base, int len, const char* mode, int other = 0) {
+    // other > 0: the plane's second dimension, appended when the image and polar families share the kernel's template length
+    // (1280x720 frames: both have 720 rows) so that their launches are not timed as one stage
+    char b[64];
+    if (other > 0) snprintf(b, sizeof(b), "%s<%d,%s>/%d", base, len, mode, other); else snprintf(b, sizeof(b), "%s<%d,%s>", base, len, mode);
+    return b;
 }
+// second dimension to tag an A-type stage of family f with (0: no clash)
+inline int a_tag(const nik_ctx* c, const Family& f) { return c->img.g.rows == c->pol.g.rows ? f.g.cols : 0; }
+inline int b_tag(const nik_ctx* c, const Family& f) { return c->img.g.cols == c->pol.g.cols ? f.g.rows : 0; }
 inline double Rb(const Family& f) { return 4.0 * (double)f.real_elems; }     // real plane bytes
 inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // half-spectrum plane bytes
 
@@ -449,24 +456,24 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
             launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W);
             d_u8 = L.u8tmp;
         }
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "u8").c_str(), n * (N + Cb(I)));
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "u8", a_tag(c, I)).c_str(), n * (N + Cb(I)));
         launch_A_fwd_u8(s, n, c->img.g, c->img.t, d_u8, c->img.real_elems, c->W, c->arena_u8, c->u8_stride, c->u8_pitch, dst, L.tmpA, c->spec_max);
     } else {
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "plane").c_str(), n * (Rb(I) + Cb(I)));
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "plane", a_tag(c, I)).c_str(), n * (Rb(I) + Cb(I)));
         launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max);
     }
     // IFFT(|F|) is real and even and the polar gather only reads the inscribed circle: columns |c| <= Rmax + 1 suffice
     const int need = c->zz_half ? std::min(c->H / 2, c->W / 2) + 1 : 0;
-    { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv").c_str(), n * 3 * Cb(I));
+    { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv", b_tag(c, I)).c_str(), n * 3 * Cb(I));
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
                            L.gbuf, c->spec_max, need); }
-    { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted").c_str(), n * (Cb(I) + Rb(I)));
+    { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)));
       launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need); }
     launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
-    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar").c_str(), n * (Rb(I) + Cb(P)));
+    { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar", a_tag(c, P)).c_str(), n * (Rb(I) + Cb(P)));
       launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max); }
     if (defer_polar_B) return;
-    { Stage st(c, L, kname("kB", c->PC, "fwd").c_str(), n * 2 * Cb(P));
+    { Stage st(c, L, kname("kB", c->PC, "fwd", b_tag(c, P)).c_str(), n * 2 * Cb(P));
       launch_B_fwd(s, n, c->pol.g, c->pol.t, L.tmpA, c->spec_max, c->arena_P, c->pol.spec_elems, dst); }
 }
 
@@ -484,25 +491,25 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
         // key-side kernel Kzz comes from the slot cache (ensure_kzz ran before): only the xz half is computed
         float2* kz = (&f == &c->pol) ? c->arena_KzP : c->arena_KzF;
         unsigned* mz = (&f == &c->pol) ? c->arena_MzP : c->arena_MzF;
-        { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv_x" : "mul_inv_x").c_str(), n * 3 * Cb(f) + xs_bytes);
+        { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv_x" : "mul_inv_x", b_tag(c, f)).c_str(), n * 3 * Cb(f) + xs_bytes);
           launch_B_mul_inv_x(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
                              xstore, xstore_stride, xstore_slot); }
-        { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_x").c_str(), n * 2 * Cb(f));
+        { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_x", a_tag(c, f)).c_str(), n * 2 * Cb(f));
           launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 1, 1); }
-        { Stage st(c, L, kname("kB", f.g.cols, "solve_cached").c_str(), n * 3 * Cb(f));
+        { Stage st(c, L, kname("kB", f.g.cols, "solve_cached", b_tag(c, f)).c_str(), n * 3 * Cb(f));
           launch_B_solve_cached(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, kz, f.spec_elems, mz, z_idx,
                                 c->cfg.lambda, L.gbuf, c->spec_max); }
     } else {
-    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv").c_str(), n * 4 * Cb(f) + xs_bytes);
+    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv", b_tag(c, f)).c_str(), n * 4 * Cb(f) + xs_bytes);
       launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
                        xstore, xstore_stride, xstore_slot, c->zz_half); }
-    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd").c_str(), n * 4 * Cb(f));
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd", a_tag(c, f)).c_str(), n * 4 * Cb(f));
       launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 0, 2, c->zz_half); }
-    { Stage st(c, L, kname("kB", f.g.cols, "solve_inv").c_str(), n * 3 * Cb(f));
+    { Stage st(c, L, kname("kB", f.g.cols, "solve_inv", b_tag(c, f)).c_str(), n * 3 * Cb(f));
       launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, c->zz_half); }
     }
     const int nb = argmax_blocks(f.g);
-    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, win.row ? "argmax_win" : "argmax").c_str(), n * Cb(f));
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, win.row ? "argmax_win" : "argmax", a_tag(c, f)).c_str(), n * Cb(f));
       if (win.row) launch_A_inv_argmax_win(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror);
       else launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
     launch_finalize(s, n, L.partials, c->partial_stride, nb, out, rot_index, n_hyp, c->PD);
@@ -532,11 +539,11 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
     if (img_u8) {
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot8").c_str(), nt * (1.0 * c->img.real_elems + Cb(c->img)));
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot8", a_tag(c, c->img)).c_str(), nt * (1.0 * c->img.real_elems + Cb(c->img)));
         launch_A_fwd_rot8(s, nt, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_TIMG), c->rot_tab,
                           didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
     } else {
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot").c_str(), nt * (Rb(c->img) + Cb(c->img)));
+        Stage st(c, L, kname("kA_fwd", c->H / 2, "rot", a_tag(c, c->img)).c_str(), nt * (Rb(c->img) + Cb(c->img)));
         launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_tab,
                          didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
     }
@@ -979,11 +986,11 @@ static int ensure_kzz_run(nik_ctx* c, Lane& L, const std::vector<nik_frame>& tod
             unsigned* mz = fam ? c->arena_MzF : c->arena_MzP;
             if (c->cfg.kernel == 1)
                 launch_energy(L.stream, m, f.g, zsrc, f.spec_elems, didx(L, IX_KEY), zsrc, f.spec_elems, didx(L, IX_KEY), L.energy);
-            { Stage st(c, L, kname("kB", f.g.cols, "zz_inv").c_str(), m * 2 * Cb(f));
+            { Stage st(c, L, kname("kB", f.g.cols, "zz_inv", b_tag(c, f)).c_str(), m * 2 * Cb(f));
               launch_B_zz_inv(L.stream, m, f.g, f.t, zsrc, f.spec_elems, didx(L, IX_KEY), L.kbuf, item_stride, L.maxbuf); }
-            { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_z").c_str(), m * 2 * Cb(f));
+            { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd_z", a_tag(c, f)).c_str(), m * 2 * Cb(f));
               launch_A_inv_kernel_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, c->spec_max, kernel_fn(c), L.maxbuf, L.energy, 0, 1); }
-            { Stage st(c, L, kname("kB", f.g.cols, "fwd_kzz").c_str(), m * 2 * Cb(f));
+            { Stage st(c, L, kname("kB", f.g.cols, "fwd_kzz", b_tag(c, f)).c_str(), m * 2 * Cb(f));
               launch_B_fwd(L.stream, m, f.g, f.t, L.kbuf, item_stride, kz, f.spec_elems, didx(L, IX_KEY)); }
             launch_store_mzz(L.stream, m, f.g, L.maxbuf, didx(L, IX_KEY), mz);
         }
@@ -1285,6 +1292,25 @@ int nik_rgb_to_gray_dev(nik_ctx* c, int n, const uint8_t* d_rgb, int bgr, uint8_
     launch_rgb2gray(c->lanes[0].stream, d_rgb, d_gray, (size_t)n * c->img.real_elems, bgr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->lanes[0].stream));
+    return NIK_OK;
+}
+
+// nik_rgb_to_gray_dev without the host synchronisation: converted on the first stream, every stream of the context waits
+// for it on the device; d_gray must not still be read by calls enqueued earlier (use two buffers, or the same buffer
+// only after nik_synchronize) -- stream order covers calls enqueued LATER
+int nik_rgb_to_gray_async(nik_ctx* c, int n, const uint8_t* d_rgb, int bgr, uint8_t* d_gray) {
+    if (!c || !d_rgb || !d_gray || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (n == 0) return NIK_OK;
+    if (!c->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fence_ev, hipEventDisableTiming));
+    // the conversion overwrites d_gray: it must come after whatever the other streams still read from it
+    for (int li = 1; li < c->active_lanes; ++li) {
+        HIP_TRY(c, hipEventRecord(c->fence_ev, c->lanes[li].stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->lanes[0].stream, c->fence_ev, 0));
+    }
+    launch_rgb2gray(c->lanes[0].stream, d_rgb, d_gray, (size_t)n * c->img.real_elems, bgr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->fence_ev, c->lanes[0].stream));
+    for (int li = 1; li < c->active_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->fence_ev, 0));
     return NIK_OK;
 }
 

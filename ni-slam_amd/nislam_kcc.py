@@ -33,7 +33,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
            "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
-           "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_group_shard", "nik_group_pick_best", "nik_group_comm_ranks",
+           "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_rgb_to_gray_async", "nik_group_shard", "nik_group_pick_best", "nik_group_comm_ranks",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
            "nik_group_match"]
 
@@ -191,6 +191,7 @@ def load():
         L.nik_match.argtypes = [P, I, I, P, P, P, P]
         L.nik_match_topk.argtypes = [P, I, I, P, I, P, P, P]
         L.nik_rgb_to_gray_dev.argtypes = [P, I, P, I, P]
+        L.nik_rgb_to_gray_async.argtypes = [P, I, P, I, P]
         L.nik_dbg_fft.argtypes = [P, I, P, P]
         L.nik_dbg_ifft.argtypes = [P, I, P, P]
         L.nik_dbg_rotate.argtypes = [P, I, I, P]
@@ -480,6 +481,10 @@ class CorrelationFlow:
     def rgb_to_gray_dev(self, d_rgb_ptr, n, d_gray_ptr, bgr=False):
         self._chk(self._L.nik_rgb_to_gray_dev(self._ctx, int(n), C.c_void_p(int(d_rgb_ptr)), int(bool(bgr)),
                                               C.c_void_p(int(d_gray_ptr))))
+
+    def rgb_to_gray_async(self, d_rgb_ptr, n, d_gray_ptr, bgr=False):
+        self._chk(self._L.nik_rgb_to_gray_async(self._ctx, int(n), C.c_void_p(int(d_rgb_ptr)), int(bool(bgr)),
+                                                C.c_void_p(int(d_gray_ptr))))
 
     # ---- measurement -------------------------------------------------------------------------
     def profile_enable(self, on=True):

@@ -81,10 +81,11 @@ def test_group_through_rccl_single_rank():
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-def _run_bench(world, gb, dump, tmp_path):
+def _run_bench(world, gb, dump, tmp_path, workload="pairs"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NIK_BENCH_GLOBAL_BATCH=str(gb), NIK_BENCH_DUMP=str(dump), NIK_BENCH_DEVICE="0", NIK_BENCH_BACKEND="gloo")
-    common = ["bench.py", "--gpus", str(world), "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-profile", "--no-cached"]
+    common = ["bench.py", "--gpus", str(world), "--workload", workload, "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-profile", "--no-cached",
+              "--no-live-prof"]
     if world == 1:
         cmd = [sys.executable] + common
     else:
@@ -113,3 +114,22 @@ def test_two_ranks_on_one_device_equal_one_rank(tmp_path):
     assert parts == whole
     s1 = np.array(d1[0]["stats"]); s2 = np.array(d2[0]["stats"])
     assert s1[3] == gb == s2[3] and np.allclose(s1, s2, rtol=1e-12, atol=0) and np.array_equal(np.array(d2[1]["stats"]), s2)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_configs3_hd_two_ranks_equal_one_rank(tmp_path):
+    """BASELINE configs[3] as written -- 1280x720 RGB pairs sharded over the ranks with the residual all-reduce -- runs through
+    bench.py's multi-rank path (`--workload hd --gpus N`): two ranks on one device give the unsharded run's results bit for
+    bit, and the line carries the machine-checkable multi-GPU facts."""
+    gb = 12
+    line1, d1 = _run_bench(1, gb, tmp_path / "h1", tmp_path, "hd")
+    line2, d2 = _run_bench(2, gb, tmp_path / "h2", tmp_path, "hd")
+    assert "1280x720" in line2["metric"] and line2["n_gpus"] == 2
+    assert d2[0]["results"] + d2[1]["results"] == d1[0]["results"] and len(d1[0]["results"]) == gb
+    s1 = np.array(d1[0]["stats"]); s2 = np.array(d2[0]["stats"])
+    assert s1[3] == gb == s2[3] and np.allclose(s1, s2, rtol=1e-12, atol=0)
+    mg = line2["multi_gpu"]
+    assert mg["world"] == 2 and mg["fallback"] is False and mg["rccl_ranks"] == 0        # (gloo test hook: no RCCL communicator)
+    assert 0 < mg["pairs_per_s_per_rank_min"] <= mg["pairs_per_s_per_rank_max"]
+    assert line1["multi_gpu"]["world"] == 1
