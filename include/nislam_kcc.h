@@ -334,6 +334,22 @@ typedef struct {
 /* poses: n_poses x (x, y, yaw), updated in place; ids: their frame ids (must contain 0); max_iterations <= 0: 300. */
 int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* poses, int n_constraints,
                             const nik_pg_constraint* constraints, int max_iterations, nik_pg_summary* summary);
+/* The same solver with the residuals and the normal equations (J^T J blocks, J^T r, cost) evaluated on HIP device `device`
+ * (kcc_posegraph_dev.hip: one thread per constraint, a gather per free pose over its incident constraints, a wave-shuffle
+ * reduction of the cost -- all in double, fixed summation orders); the damped solve stays on the host. */
+int nik_pose_graph_optimize_dev(int device, int n_poses, const int32_t* ids, double* poses, int n_constraints,
+                                const nik_pg_constraint* constraints, int max_iterations, nik_pg_summary* summary);
+/* cost = 0.5 sum |r|^2, gradient J^T r [n_poses][3] and the J^T J diagonal blocks [n_poses][9] at `poses` (rows of the constant
+ * pose and of poses no constraint touches are zero); device < 0: on the host.  Outputs may be NULL. */
+int nik_pose_graph_linearize(int device, int n_poses, const int32_t* ids, const double* poses, int n_constraints,
+                             const nik_pg_constraint* constraints, double* cost, double* gradient, double* jtj_diag);
+/* A shard of the constraints resident on one GPU, and its cost left on that device (one double, valid after the work on
+ * *stream, a hipStream_t): the operand of nik_group_pose_graph_cost. */
+typedef struct nik_pg_shard nik_pg_shard;
+int  nik_pg_shard_create(int device, int n_poses, const int32_t* ids, const double* poses, int n_constraints,
+                         const nik_pg_constraint* constraints, nik_pg_shard** out);
+void nik_pg_shard_destroy(nik_pg_shard* s);
+int  nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses /* NULL: unchanged */, double** d_cost, void** stream);
 
 /* the tracker's pose graph: Map::_edges as OptimizeMap would feed them to the solver (robot units, identity information;
  * types[i]: 0 = KCC edge between consecutive keyframes, 1 = loop edge), and how often CheckAndOptimize has optimised */
@@ -420,6 +436,9 @@ int  nik_group_comm_ranks(const nik_group* g);
  * reduced on the devices and all-reduced with RCCL; asynchronous when out == NULL (fetch with nik_group_residual_result) */
 int  nik_group_allreduce_residual(nik_group* g, double out[4]);
 int  nik_group_residual_result(nik_group* g, double out[4]);      /* once per all-reduce: a second fetch is NIK_ERR_NOT_READY */
+/* cost of a pose graph whose constraints are sharded over the group (shards[i]: local member i's nik_pg_shard, on its
+ * device): each GPU reduces its shard, ONE double is all-reduced with RCCL ("the final pose-graph residual sum") */
+int  nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const double* poses, double* cost);
 /* every local member's best candidate (global index, -1: none) -> the group's winner by the reference's rule */
 int  nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_result* local_best, int* best_index, nik_pose_result* best);
 /* local groups: a batch of n pairs (host u8 images) sharded over the GPUs; keys[i] / cur_dst[i] are slots of the member

@@ -11,9 +11,9 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # -fno-slp-vectorize: packed FP32 (v_pk_*) buys no throughput on gfx950 and costs register shuffles (measured +9 %)
 UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_group.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
          ("kcc_camera.cpp", ["-ffp-contract=off"]), ("kcc_map.cpp", ["-ffp-contract=off"]),
-         ("kcc_posegraph.cpp", ["-ffp-contract=off"]), ("kcc_pyramid.cpp", ["-ffp-contract=off"]),
+         ("kcc_posegraph.cpp", ["-ffp-contract=off"]), ("kcc_posegraph_dev.hip", ["-ffp-contract=off"]), ("kcc_pyramid.cpp", ["-ffp-contract=off"]),
          ("kcc_stitcher.hip", ["-ffp-contract=off"])]
-HEADERS = ["kcc_tables.h", "kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
+HEADERS = ["kcc_posegraph_dev.h", "kcc_tables.h", "kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
 
 
 def _stale(target, deps):

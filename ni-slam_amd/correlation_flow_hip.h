@@ -17,8 +17,19 @@
 //     std::invalid_argument("Received invalid kernel type") at ComputePose time (:167-168);
 //   * single-threaded, synchronous, non-reentrant (one context; shared via shared_ptr like :33).
 // Differences: no std::cout of pose/info (:139-140) and no dead `rectify` warp (:141).
+//
+// Frame side table.  The reference API hands spectra around BY VALUE (MapBuilder keeps `_last_fft_result` /
+// `_last_fft_polar` copies and passes them back, src/map_builder.cc:72-75,99-106,127-131), which taken literally means a
+// 5 MB host -> device import per ComputePose.  The adaptor therefore remembers which device slot holds what it exported: every
+// array it fills in ComputeIntermedium is fingerprinted (dimensions + 64 samples spread over the array, FNV-1a), and
+// ComputePose looks the fingerprints of its arguments up before importing anything.  MapBuilder's pattern -- the arrays it
+// passes are the ones ComputeIntermedium produced, or copies of them -- then runs without any import; arrays the table does not
+// know (edited, or produced elsewhere) are imported exactly as before.  A fingerprint is not a checksum: code that edits a
+// few elements of an exported spectrum in place and expects the edit to be honoured must call forget() (or define
+// NISLAM_KCC_NO_FRAME_TABLE).  stats() counts hits and imports.
 #pragma once
 
+#include <cstdint>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -48,13 +59,15 @@ inline nik_config to_nik_config(const CFConfigT& c) {
 template <class ArrayXXf, class ArrayXXcf, class Vector3d>
 class CorrelationFlowT {
 public:
+    struct Stats { long table_hits = 0, imports = 0, intermedia = 0, poses = 0; };
+
     template <class CFConfigT>
     CorrelationFlowT(CFConfigT& cf_config, double& image_height, double& image_width, int device = 0)
         : H_((int)image_height), W_((int)image_width) {
         nik_config n = to_nik_config(cf_config);
         PD_ = n.rotation_divisor; PC_ = n.rotation_channel;
-        // slots: 0 = key (last_fft_*), 1 = current; batch of 1 pair (the reference's call pattern)
-        const int rc = nik_create(&n, H_, W_, /*max_batch=*/1, /*max_frames=*/2, device, &ctx_);
+        // batch of 1 pair (the reference's call pattern); SLOTS device frames remembered by the side table
+        const int rc = nik_create(&n, H_, W_, /*max_batch=*/1, /*max_frames=*/SLOTS, device, &ctx_);
         if (rc != NIK_OK) throw std::runtime_error(std::string("nik_create: ") + nik_last_error(nullptr));
     }
     ~CorrelationFlowT() { nik_destroy(ctx_); }
@@ -63,39 +76,91 @@ public:
 
     // void ComputeIntermedium(const ArrayXXf&, ArrayXXcf&, ArrayXXcf&)      correlation_flow.cc:89-95
     void ComputeIntermedium(const ArrayXXf& image, ArrayXXcf& fft_result, ArrayXXcf& fft_polar) {
-        check(nik_intermedium_f32(ctx_, image.data(), 1));
+        const int s = victim(-1);
+        check(nik_intermedium_f32(ctx_, image.data(), s));
         fft_result.resize(H_ / 2 + 1, W_);
         fft_polar.resize(PD_ / 2 + 1, PC_);
-        check(nik_frame_export(ctx_, 1, nullptr, reinterpret_cast<float*>(fft_result.data()),
+        check(nik_frame_export(ctx_, s, nullptr, reinterpret_cast<float*>(fft_result.data()),
                                reinterpret_cast<float*>(fft_polar.data())));
+        Slot& e = tab_[s];
+        e.img = print(image.data(), (size_t)H_ * W_); e.F = print(fft_result.data(), (size_t)(H_ / 2 + 1) * W_ * 2);
+        e.P = print(fft_polar.data(), (size_t)(PD_ / 2 + 1) * PC_ * 2);
+        e.has_img = e.has_F = e.has_P = true; e.age = ++clock_;
+        stats_.intermedia += 1;
     }
 
     // Vector3d ComputePose(last_fft_result, image, last_fft_polar, fft_polar, pose&, not_large_rotation)   :97-143
     Vector3d ComputePose(const ArrayXXcf& last_fft_result, const ArrayXXf& image, const ArrayXXcf& last_fft_polar,
                          const ArrayXXcf& fft_polar, Vector3d& pose, bool not_large_rotation) {
-        check(nik_frame_import(ctx_, 0, image.data() /*flag only: key image is never read*/,
-                               reinterpret_cast<const float*>(last_fft_result.data()),
-                               reinterpret_cast<const float*>(last_fft_polar.data())));
-        // the current frame contributes its image and polar spectrum; its fft_result is not an input of ComputePose
-        check(nik_frame_import(ctx_, 1, image.data(), reinterpret_cast<const float*>(last_fft_result.data()),
-                               reinterpret_cast<const float*>(fft_polar.data())));
+        const uint64_t fF = print(last_fft_result.data(), (size_t)(H_ / 2 + 1) * W_ * 2), fKP = print(last_fft_polar.data(), (size_t)(PD_ / 2 + 1) * PC_ * 2);
+        const uint64_t fI = print(image.data(), (size_t)H_ * W_), fXP = print(fft_polar.data(), (size_t)(PD_ / 2 + 1) * PC_ * 2);
+        // key frame: its two spectra (its image is never read)
+        int k = -1, c = -1;
+        for (int s = 0; s < SLOTS && table_on(); ++s) if (tab_[s].has_F && tab_[s].has_P && tab_[s].F == fF && tab_[s].P == fKP) k = s;
+        if (k < 0) {
+            k = victim(-1);
+            check(nik_frame_import(ctx_, k, image.data() /*flag only: the key image is never read*/,
+                                   reinterpret_cast<const float*>(last_fft_result.data()), reinterpret_cast<const float*>(last_fft_polar.data())));
+            Slot& e = tab_[k]; e.F = fF; e.P = fKP; e.has_F = e.has_P = true; e.has_img = false; e.age = ++clock_;
+            stats_.imports += 1;
+        } else { tab_[k].age = ++clock_; stats_.table_hits += 1; }
+        // current frame: its image and polar spectrum (its fft_result is not an input of ComputePose)
+        for (int s = 0; s < SLOTS && table_on(); ++s) if (s != k && tab_[s].has_img && tab_[s].has_P && tab_[s].img == fI && tab_[s].P == fXP) c = s;
+        if (c < 0 && table_on() && tab_[k].has_img && tab_[k].img == fI && tab_[k].P == fXP) c = k;      // a frame registered against itself
+        if (c < 0) {
+            c = victim(k);
+            check(nik_frame_import(ctx_, c, image.data(), reinterpret_cast<const float*>(last_fft_result.data()),
+                                   reinterpret_cast<const float*>(fft_polar.data())));
+            Slot& e = tab_[c]; e.img = fI; e.P = fXP; e.has_img = e.has_P = true; e.has_F = false; e.age = ++clock_;
+            stats_.imports += 1;
+        } else { tab_[c].age = ++clock_; stats_.table_hits += 1; }
         double p[3], i[3];
-        const int rc = nik_pose(ctx_, 0, 1, not_large_rotation ? 1 : 0, p, i, nullptr);
+        const int rc = nik_pose(ctx_, k, c, not_large_rotation ? 1 : 0, p, i, nullptr);
         if (rc == NIK_ERR_INVALID_KERNEL) throw std::invalid_argument("Received invalid kernel type");
         check(rc);
         Vector3d info;
-        for (int k = 0; k < 3; ++k) { pose[k] = p[k]; info[k] = i[k]; }
+        for (int q = 0; q < 3; ++q) { pose[q] = p[q]; info[q] = i[q]; }
+        stats_.poses += 1;
         return info;
     }
 
+    void forget() { for (Slot& e : tab_) e = Slot(); }      // drop the side table (arrays edited in place)
+    const Stats& stats() const { return stats_; }
     nik_ctx* context() const { return ctx_; }      // for batched / device-resident use beyond the reference API
 
 private:
+    enum { SLOTS = 8 };
+    struct Slot { uint64_t img = 0, F = 0, P = 0; bool has_img = false, has_F = false, has_P = false; unsigned long age = 0; };
+    static bool table_on() {
+#ifdef NISLAM_KCC_NO_FRAME_TABLE
+        return false;
+#else
+        return true;
+#endif
+    }
+    // fingerprint of an array of n floats: its length and 64 samples spread evenly over it (bit patterns), FNV-1a
+    template <class T> static uint64_t print(const T* data, size_t n_floats) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(data);
+        uint64_t h = 1469598103934665603ull ^ (uint64_t)n_floats;
+        const size_t step = n_floats / 64 ? n_floats / 64 : 1;
+        for (size_t i = 0, k = 0; k < 64 && i < n_floats; ++k, i += step) { h ^= w[i] + 0x9E3779B97F4A7C15ull * (k + 1); h *= 1099511628211ull; }
+        if (n_floats) { h ^= w[n_floats - 1]; h *= 1099511628211ull; }
+        return h;
+    }
+    int victim(int keep) {                            // least recently used slot other than `keep`
+        int v = -1;
+        for (int s = 0; s < SLOTS; ++s) if (s != keep && (v < 0 || tab_[s].age < tab_[v].age)) v = s;
+        tab_[v] = Slot();
+        return v;
+    }
     void check(int rc) const {
         if (rc != NIK_OK) throw std::runtime_error(std::string("nislam_kcc: ") + nik_last_error(ctx_));
     }
     nik_ctx* ctx_ = nullptr;
     int H_, W_, PD_ = 0, PC_ = 0;
+    Slot tab_[SLOTS];
+    unsigned long clock_ = 0;
+    Stats stats_;
 };
 
 }  // namespace nislam_kcc

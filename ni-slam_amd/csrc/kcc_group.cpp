@@ -359,6 +359,49 @@ int nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_
     return NIK_OK;
 }
 
+// The pose graph's cost over constraints SHARDED across the group (north star: "RCCL all-reduce ... only for the final
+// pose-graph residual sum"): member i holds shard shards[i] (nik_pg_shard_create on ITS device: the constraints its own frame
+// pairs produced), evaluates 0.5 sum |r|^2 of its shard at `poses` on the device (kcc_posegraph_dev.hip: wave-shuffle
+// reduction) and the group sums the per-member doubles with one ncclAllReduce.  poses: [n_poses][3] as given to the shards
+// (NULL: the poses of the previous call).  Every member of a rank group must call it (a collective).
+int nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const double* poses, double* cost) {
+    if (!g || !shards || !cost) return NIK_ERR_INVALID_ARG;
+    const bool multi = g->use_rccl;
+    std::vector<double*> src(g->m.size(), nullptr);
+    std::vector<hipStream_t> st(g->m.size(), nullptr);
+    for (size_t i = 0; i < g->m.size(); ++i) {
+        Member& mb = g->m[i];
+        G_HIP(g, hipSetDevice(mb.device));
+        void* s = nullptr;
+        int rc = nik_pg_shard_cost_dev(shards[i], poses, &src[i], &s);
+        if (rc) return gfail(g, rc, "nik_pg_shard_cost_dev failed");
+        st[i] = (hipStream_t)s;
+    }
+    std::string first_err;
+    if (multi) G_NCCL(g, rccl().GroupStart());
+    for (size_t i = 0; i < g->m.size() && first_err.empty(); ++i) {
+        Member& mb = g->m[i];
+        hipError_t he = hipSetDevice(mb.device);
+        if (he != hipSuccess) { first_err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
+        if (multi) {
+            const ncclResult_t nr = rccl().AllReduce(src[i], mb.d_buf, 1, ncclDouble, ncclSum, mb.comm, st[i]);
+            if (nr != ncclSuccess) first_err = std::string("ncclAllReduce: ") + rccl().GetErrorString(nr);
+        } else {
+            he = hipMemcpyAsync(mb.d_buf, src[i], sizeof(double), hipMemcpyDeviceToDevice, st[i]);
+            if (he != hipSuccess) first_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he);
+        }
+    }
+    if (multi) { const ncclResult_t nr = rccl().GroupEnd(); if (nr != ncclSuccess && first_err.empty()) first_err = std::string("ncclGroupEnd: ") + rccl().GetErrorString(nr); }
+    if (!first_err.empty()) return gfail(g, NIK_ERR_HIP, first_err);
+    Member& m0 = g->m[0];
+    G_HIP(g, hipSetDevice(m0.device));
+    G_HIP(g, hipMemcpyAsync(m0.h_buf, m0.d_buf, sizeof(double), hipMemcpyDeviceToHost, st[0]));
+    for (size_t i = 0; i < g->m.size(); ++i) { G_HIP(g, hipSetDevice(g->m[i].device)); G_HIP(g, hipStreamSynchronize(st[i])); }
+    // (a local group without RCCL -- one member -- has nothing to add up; with several local members RCCL summed them)
+    *cost = m0.h_buf[0];
+    return NIK_OK;
+}
+
 // ---- one process, every GPU: sharded batches ---------------------------------------------------------------
 
 // n frame pairs (host u8 images, h_gray[n][H*W]) registered against resident key frames; pair i runs on member

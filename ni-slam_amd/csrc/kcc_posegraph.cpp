@@ -15,10 +15,12 @@
 // dense Cholesky for small graphs and block-Jacobi preconditioned conjugate gradients for large ones.
 // Per keyframe insertion with >= 2 loop matches, not per frame: host code, double precision.
 #include "../../include/nislam_kcc.h"
+#include "kcc_posegraph_dev.h"
 
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <string>
 #include <vector>
 
 namespace {
@@ -214,15 +216,11 @@ bool solve(const Problem& P, const Normal& N, const std::vector<double>& damp, s
 
 }  // namespace
 
-extern "C" int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* poses, int n_constraints,
-                                       const nik_pg_constraint* cons, int max_iterations, nik_pg_summary* summary) {
-    if (n_poses < 0 || n_constraints < 0 || (n_poses > 0 && (!ids || !poses)) || (n_constraints > 0 && !cons)) return NIK_ERR_INVALID_ARG;
-    nik_pg_summary sm{}; sm.termination = NIK_PG_NO_CONSTRAINTS;
-    if (n_constraints == 0) { if (summary) *summary = sm; return NIK_OK; }        // "No constraints, no problem to optimize." (pose_graph_2d.cc:58-61)
+// the problem BuildOptimizationProblem hands to Ceres (pose_graph_2d.cc:53-109), from the C ABI's arrays
+static int setup(int n_poses, const int32_t* ids, const double* poses, int n_constraints, const nik_pg_constraint* cons, Problem& P) {
     std::map<int, int> index;
     for (int i = 0; i < n_poses; ++i) if (!index.emplace(ids[i], i).second) return NIK_ERR_INVALID_ARG;
     if (!index.count(0)) return NIK_ERR_INVALID_ARG;                               // CHECK(baseframe_pose_iter != poses->end())  (:104)
-    Problem P;
     P.n = n_poses; P.x.assign(poses, poses + (size_t)3 * n_poses); P.fixed.assign(n_poses, 0);
     P.fixed[index[0]] = 1;
     P.edges.resize(n_constraints);
@@ -237,19 +235,65 @@ extern "C" int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* 
     }
     // poses that no constraint touches are not part of the problem (Ceres never sees them)
     P.col.assign(n_poses, -1);
+    P.dim = 0;
     for (int i = 0; i < n_poses; ++i) if (used[i] && !P.fixed[i]) { P.col[i] = P.dim; P.dim += 3; }
+    return NIK_OK;
+}
 
-    std::vector<double> r, J, rn, step, damp(P.dim), xn;
+// the problem's device twin (kcc_posegraph_dev.hip): residuals, J^T J blocks and J^T r evaluated on `device`
+static kcc_pg::DevProblem* to_device(const Problem& P, int device, std::string& err) {
+    std::vector<kcc_pg::DevEdge> de(P.edges.size());
+    for (size_t e = 0; e < P.edges.size(); ++e) {
+        const Edge& E = P.edges[e];
+        de[e].a = E.a; de[e].b = E.b; de[e].ca = P.col[E.a]; de[e].cb = P.col[E.b];
+        for (int k = 0; k < 3; ++k) de[e].m[k] = E.m[k];
+        for (int k = 0; k < 9; ++k) de[e].L[k] = E.L[k];
+    }
+    return kcc_pg::dev_create(device, P.n, P.dim, de, P.col, err);
+}
+
+// device < 0: residuals and normal equations on the host; else on that HIP device (the solve stays on the host)
+static int optimize(int device, int n_poses, const int32_t* ids, double* poses, int n_constraints,
+                    const nik_pg_constraint* cons, int max_iterations, nik_pg_summary* summary) {
+    if (n_poses < 0 || n_constraints < 0 || (n_poses > 0 && (!ids || !poses)) || (n_constraints > 0 && !cons)) return NIK_ERR_INVALID_ARG;
+    nik_pg_summary sm{}; sm.termination = NIK_PG_NO_CONSTRAINTS;
+    if (n_constraints == 0) { if (summary) *summary = sm; return NIK_OK; }        // "No constraints, no problem to optimize." (pose_graph_2d.cc:58-61)
+    Problem P;
+    int rc = setup(n_poses, ids, poses, n_constraints, cons, P);
+    if (rc) return rc;
+    kcc_pg::DevProblem* dev = nullptr;
+    if (device >= 0) {
+        std::string err;
+        dev = to_device(P, device, err);
+        if (!dev) return NIK_ERR_HIP;
+    }
+    struct Guard { kcc_pg::DevProblem* d; ~Guard() { kcc_pg::dev_destroy(d); } } guard{ dev };
+    // linearise at xs: residual cost, and (want_normal) the Gauss-Newton blocks into N
+    std::vector<double> r_, J_;
+    auto linearize = [&](const std::vector<double>& xs, double& cost_out, Normal* N) -> bool {
+        if (dev) {
+            if (N) {
+                N->dim = P.dim; N->diag.assign((size_t)(P.dim / 3) * 9, 0.0); N->off.assign(P.edges.size() * 9, 0.0); N->g.assign(P.dim, 0.0);
+                return kcc_pg::dev_linearize(dev, xs.data(), &cost_out, nullptr, N->diag.data(), N->off.data(), N->g.data()) == 0;
+            }
+            return kcc_pg::dev_linearize(dev, xs.data(), &cost_out, nullptr, nullptr, nullptr, nullptr) == 0;
+        }
+        P.eval(xs, r_, N ? &J_ : nullptr);
+        cost_out = Problem::cost(r_);
+        if (N) build_normal(P, r_, J_, *N);
+        return true;
+    };
+
+    std::vector<double> step, damp(P.dim), xn;
     Normal N;
-    P.eval(P.x, r, &J);
-    double cost = Problem::cost(r);
+    double cost = 0;
+    if (!linearize(P.x, cost, &N)) return NIK_ERR_HIP;
     sm.initial_cost = cost;
     double radius = 1e4, decrease = 2.0;
     sm.termination = NIK_PG_NO_CONVERGENCE;
     const int max_it = max_iterations > 0 ? max_iterations : 300;
     int it = 0;
     for (; it < max_it; ++it) {
-        build_normal(P, r, J, N);
         double gmax = 0; for (double v : N.g) gmax = std::max(gmax, std::fabs(v));
         if (gmax <= 1e-10) { sm.termination = NIK_PG_CONVERGENCE; break; }          // gradient_tolerance
         for (int b = 0; b < P.dim / 3; ++b)
@@ -272,13 +316,13 @@ extern "C" int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* 
             xn[3 * i] += s[0]; xn[3 * i + 1] += s[1]; xn[3 * i + 2] = normalize_angle(xn[3 * i + 2] + s[2]);   // AngleLocalParameterization
         }
         if (std::sqrt(snorm) <= 1e-8 * (std::sqrt(xnorm) + 1e-8)) { sm.termination = NIK_PG_CONVERGENCE; break; }   // parameter_tolerance
-        P.eval(xn, rn, nullptr);
-        const double cn = Problem::cost(rn);
+        double cn = 0;
+        if (!linearize(xn, cn, nullptr)) return NIK_ERR_HIP;
         const double rho = model > 0 ? (cost - cn) / model : -1.0;
         if (rho > 1e-3) {                                                         // min_relative_decrease
             const double dc = cost - cn;
-            P.x = xn; cost = cn;
-            P.eval(P.x, r, &J);
+            P.x = xn;
+            if (!linearize(P.x, cost, &N)) return NIK_ERR_HIP;
             const double t = 2.0 * rho - 1.0;
             radius = std::min(radius / std::max(1.0 / 3.0, 1.0 - t * t * t), 1e16);
             decrease = 2.0;
@@ -294,3 +338,71 @@ extern "C" int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* 
     if (summary) *summary = sm;
     return NIK_OK;
 }
+
+extern "C" {
+
+int nik_pose_graph_optimize(int n_poses, const int32_t* ids, double* poses, int n_constraints,
+                            const nik_pg_constraint* cons, int max_iterations, nik_pg_summary* summary) {
+    return optimize(-1, n_poses, ids, poses, n_constraints, cons, max_iterations, summary);
+}
+
+int nik_pose_graph_optimize_dev(int device, int n_poses, const int32_t* ids, double* poses, int n_constraints,
+                                const nik_pg_constraint* cons, int max_iterations, nik_pg_summary* summary) {
+    if (device < 0) return NIK_ERR_INVALID_ARG;
+    return optimize(device, n_poses, ids, poses, n_constraints, cons, max_iterations, summary);
+}
+
+// cost, gradient and J^T J diagonal blocks at `poses`, by pose (zero rows for the constant pose and for poses no constraint touches)
+int nik_pose_graph_linearize(int device, int n_poses, const int32_t* ids, const double* poses, int n_constraints,
+                             const nik_pg_constraint* cons, double* cost, double* gradient /*[n_poses][3]*/, double* jtj_diag /*[n_poses][9]*/) {
+    if (n_poses <= 0 || n_constraints < 0 || !ids || !poses || (n_constraints > 0 && !cons)) return NIK_ERR_INVALID_ARG;
+    Problem P;
+    int rc = setup(n_poses, ids, poses, n_constraints, cons, P);
+    if (rc) return rc;
+    Normal N;
+    double c = 0;
+    if (device >= 0) {
+        std::string err;
+        kcc_pg::DevProblem* dev = to_device(P, device, err);
+        if (!dev) return NIK_ERR_HIP;
+        N.dim = P.dim; N.diag.assign((size_t)(P.dim / 3) * 9, 0.0); N.off.assign(P.edges.size() * 9, 0.0); N.g.assign(P.dim, 0.0);
+        const int hr = kcc_pg::dev_linearize(dev, P.x.data(), &c, nullptr, N.diag.data(), N.off.data(), N.g.data());
+        kcc_pg::dev_destroy(dev);
+        if (hr) return NIK_ERR_HIP;
+    } else {
+        std::vector<double> r, J;
+        P.eval(P.x, r, &J);
+        c = Problem::cost(r);
+        build_normal(P, r, J, N);
+    }
+    if (cost) *cost = c;
+    for (int i = 0; i < n_poses; ++i) {
+        const int col = P.col[i];
+        if (gradient) for (int k = 0; k < 3; ++k) gradient[3 * i + k] = col >= 0 ? N.g[col + k] : 0.0;
+        if (jtj_diag) for (int k = 0; k < 9; ++k) jtj_diag[9 * i + k] = col >= 0 ? N.diag[(size_t)(col / 3) * 9 + k] : 0.0;
+    }
+    return NIK_OK;
+}
+
+// a SHARD of the constraints evaluated on `device`, its cost left on the device: what nik_group_pose_graph_cost all-reduces
+struct nik_pg_shard { kcc_pg::DevProblem* dev; std::vector<double> x; };
+int nik_pg_shard_create(int device, int n_poses, const int32_t* ids, const double* poses, int n_constraints, const nik_pg_constraint* cons, nik_pg_shard** out) {
+    if (!out || device < 0 || n_poses <= 0 || !ids || !poses || n_constraints < 0 || (n_constraints > 0 && !cons)) return NIK_ERR_INVALID_ARG;
+    *out = nullptr;
+    Problem P;
+    int rc = setup(n_poses, ids, poses, n_constraints, cons, P);
+    if (rc) return rc;
+    std::string err;
+    kcc_pg::DevProblem* dev = to_device(P, device, err);
+    if (!dev) return NIK_ERR_HIP;
+    *out = new nik_pg_shard{ dev, P.x };
+    return NIK_OK;
+}
+void nik_pg_shard_destroy(nik_pg_shard* s) { if (s) { kcc_pg::dev_destroy(s->dev); delete s; } }
+int nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses, double** d_cost, void** stream) {
+    if (!s || !d_cost) return NIK_ERR_INVALID_ARG;
+    if (poses) s->x.assign(poses, poses + s->x.size());
+    return kcc_pg::dev_cost_async(s->dev, s->x.data(), d_cost, stream) ? NIK_ERR_HIP : NIK_OK;
+}
+
+}  // extern "C"

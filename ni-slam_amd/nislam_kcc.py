@@ -26,7 +26,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar", "nik_dbg_response",
            "nik_profile_enable", "nik_profile_read", "nik_set_streams", "nik_set_chunk",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
            "nik_downsample_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
@@ -148,6 +148,13 @@ def load():
         L.nik_tracker_optimizations.argtypes = [P, P]
         L.nik_map_update_poses.argtypes = [P, I, P, P]
         L.nik_pose_graph_optimize.argtypes = [I, P, P, I, P, I, P]
+        L.nik_pose_graph_optimize_dev.argtypes = [I, I, P, P, I, P, I, P]
+        L.nik_pose_graph_linearize.argtypes = [I, I, P, P, I, P, P, P, P]
+        L.nik_pg_shard_create.argtypes = [I, I, P, P, I, P, P]
+        L.nik_pg_shard_destroy.argtypes = [P]
+        L.nik_pg_shard_destroy.restype = None
+        L.nik_pg_shard_cost_dev.argtypes = [P, P, P, P]
+        L.nik_group_pose_graph_cost.argtypes = [P, P, P, P]
         L.nik_stitcher_create.argtypes = [P, I, P]
         L.nik_stitcher_destroy.argtypes = [P]
         L.nik_stitcher_destroy.restype = None
@@ -594,6 +601,15 @@ class Group:
         """ranks the RCCL communicator spans (ncclCommCount); 0 = no RCCL in use"""
         return self._L.nik_group_comm_ranks(self._g)
 
+    def pose_graph_cost(self, shards, poses=None):
+        """0.5 sum |r|^2 of a pose graph whose constraints are sharded over the group's GPUs: reduced per device, one double
+        all-reduced (shards: one PgShard per local member)"""
+        arr = (C.c_void_p * len(shards))(*[s._s for s in shards])
+        x = None if poses is None else np.ascontiguousarray(np.array(poses, np.float64))
+        cost = C.c_double(0)
+        self._chk(self._L.nik_group_pose_graph_cost(self._g, arr, _p(x) if x is not None else None, C.addressof(cost)))
+        return cost.value
+
     def allreduce_residual(self, wait=True):
         out = np.zeros(4, np.float64)
         self._chk(self._L.nik_group_allreduce_residual(self._g, _p(out) if wait else None))
@@ -738,19 +754,61 @@ class NikPgSummary(C.Structure):
                 ("initial_cost", C.c_double), ("final_cost", C.c_double)]
 
 
-def pose_graph_optimize(ids, poses, constraints, max_iterations=300):
-    """MapBuilder::OptimizeMap's solve (pose_graph_2d.cc).  ids: frame ids (0 is held fixed); poses: (n, 3) x, y, yaw;
-    constraints: iterable of (id_begin, id_end, x, y, yaw, information 3x3).  Returns (optimised poses, summary dict).
-    Host only: needs the library but no GPU."""
-    ids = np.ascontiguousarray(ids, np.int32)
-    out = np.array(poses, np.float64).reshape(len(ids), 3).copy()
+def _pg_constraints(constraints):
     cons = (NikPgConstraint * max(len(constraints), 1))()
     for k, (a, b, x, y, yaw, info) in enumerate(constraints):
         cons[k].id_begin, cons[k].id_end, cons[k].x, cons[k].y, cons[k].yaw_radians = int(a), int(b), x, y, yaw
         cons[k].information[:] = list(np.asarray(info, np.float64).reshape(9))
+    return cons
+
+
+def pose_graph_linearize(ids, poses, constraints, device=-1):
+    """cost, gradient (n, 3) and J^T J diagonal blocks (n, 3, 3) at `poses`; device < 0: host, else that HIP device"""
+    ids = np.ascontiguousarray(ids, np.int32)
+    x = np.ascontiguousarray(np.array(poses, np.float64).reshape(len(ids), 3))
+    cons = _pg_constraints(constraints)
+    cost = C.c_double(0)
+    g = np.zeros((len(ids), 3)); d = np.zeros((len(ids), 3, 3))
+    rc = load().nik_pose_graph_linearize(int(device), len(ids), _p(ids), _p(x), len(constraints), C.cast(cons, C.c_void_p), C.addressof(cost), _p(g), _p(d))
+    if rc:
+        raise NikError(rc, "nik_pose_graph_linearize failed")
+    return cost.value, g, d
+
+
+class PgShard:
+    """a shard of a pose graph's constraints resident on one GPU (nik_pg_shard): operand of Group.pose_graph_cost"""
+
+    def __init__(self, device, ids, poses, constraints):
+        ids = np.ascontiguousarray(ids, np.int32)
+        x = np.ascontiguousarray(np.array(poses, np.float64).reshape(len(ids), 3))
+        self._cons = _pg_constraints(constraints)
+        self._s = C.c_void_p()
+        rc = load().nik_pg_shard_create(int(device), len(ids), _p(ids), _p(x), len(constraints), C.cast(self._cons, C.c_void_p), C.byref(self._s))
+        if rc:
+            raise NikError(rc, "nik_pg_shard_create failed")
+
+    def close(self):
+        if getattr(self, "_s", None):
+            load().nik_pg_shard_destroy(self._s)
+            self._s = None
+
+    __del__ = close
+
+
+def pose_graph_optimize(ids, poses, constraints, max_iterations=300, device=-1):
+    """MapBuilder::OptimizeMap's solve (pose_graph_2d.cc).  ids: frame ids (0 is held fixed); poses: (n, 3) x, y, yaw;
+    constraints: iterable of (id_begin, id_end, x, y, yaw, information 3x3).  Returns (optimised poses, summary dict).
+    device < 0: host only (needs the library but no GPU); else residuals / normal equations on that HIP device."""
+    ids = np.ascontiguousarray(ids, np.int32)
+    out = np.array(poses, np.float64).reshape(len(ids), 3).copy()
+    cons = _pg_constraints(constraints)
     sm = NikPgSummary()
-    rc = load().nik_pose_graph_optimize(len(ids), _p(ids), _p(out), len(constraints), C.cast(cons, C.c_void_p), int(max_iterations),
-                                        C.addressof(sm))
+    if device >= 0:
+        rc = load().nik_pose_graph_optimize_dev(int(device), len(ids), _p(ids), _p(out), len(constraints), C.cast(cons, C.c_void_p), int(max_iterations),
+                                                C.addressof(sm))
+    else:
+        rc = load().nik_pose_graph_optimize(len(ids), _p(ids), _p(out), len(constraints), C.cast(cons, C.c_void_p), int(max_iterations),
+                                            C.addressof(sm))
     if rc:
         raise NikError(rc, "nik_pose_graph_optimize: unknown pose id / no pose 0 / information not positive definite")
     return out, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,

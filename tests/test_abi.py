@@ -74,8 +74,12 @@ def test_argument_validation_precedes_device_use(lib_path):
 def _build_adaptor_test(lib_path, tmpdir):
     import subprocess
     exe = os.path.join(str(tmpdir), "adaptor_test")
+    ora = os.path.join(ROOT, "oracle")
+    from oracle import kcc_oracle
+    kcc_oracle.build()                                       # the test's checker (libkcc_oracle.so)
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "adaptor_test.cpp"),
-                           "-I", PKG, "-L", PKG, "-Wl,-rpath," + PKG, "-lnislam_kcc_hip", "-o", exe])
+                           "-I", PKG, "-I", ora, "-L", PKG, "-L", ora, "-Wl,-rpath," + PKG, "-Wl,-rpath," + ora,
+                           "-lnislam_kcc_hip", "-lkcc_oracle", "-o", exe])
     return exe
 
 

@@ -119,3 +119,79 @@ def test_known_answers_and_errors():
     # poses that no constraint touches are left alone
     got, sm = N.pose_graph_optimize([0, 1, 2], [[0, 0, 0], [1.2, 0.1, 0], [9, 9, 9]], [(0, 1, 1, 0, 0, I)])
     assert got[2] == pytest.approx([9, 9, 9]) and got[1] == pytest.approx([1, 0, 0], abs=1e-6)
+
+
+# ---- the same problem linearised on the device (kcc_posegraph_dev.hip) ----------------------------------------------
+
+def test_host_linearisation_matches_the_independent_jacobian():
+    """nik_pose_graph_linearize on the host against the numpy residual / Jacobian written from the error term"""
+    N = nik()
+    ids, guess, cons = make_graph(40, 8, [(0, 39), (7, 30)])
+    cost, g, d = N.pose_graph_linearize(ids, guess, cons, device=-1)
+    r = residuals(guess[1:].reshape(-1), ids, guess[0], cons)
+    J = jacobian(guess[1:].reshape(-1), ids, guess[0], cons)
+    assert cost == pytest.approx(0.5 * float(r @ r), rel=1e-13)
+    assert np.allclose(g[1:].reshape(-1), J.T @ r, rtol=1e-11, atol=1e-12) and np.all(g[0] == 0)
+    H = J.T @ J
+    for k in range(1, 40):
+        assert np.allclose(d[k], H[3 * (k - 1):3 * k, 3 * (k - 1):3 * k], rtol=1e-11, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,loops,seed", [(12, [(0, 11), (3, 9)], 1), (300, [(0, 299), (20, 180), (100, 250), (50, 290), (130, 140)], 3)])
+def test_device_linearisation_and_solve_match_the_host(n, loops, seed):
+    N = nik()
+    ids, guess, cons = make_graph(n, seed, loops)
+    ch, gh, dh = N.pose_graph_linearize(ids, guess, cons, device=-1)
+    cd, gd, dd = N.pose_graph_linearize(ids, guess, cons, device=0)
+    # same double arithmetic; only the order of the sums over a pose's constraints / over the constraints may differ
+    assert cd == pytest.approx(ch, rel=1e-13)
+    assert np.allclose(gd, gh, rtol=1e-12, atol=1e-13) and np.allclose(dd, dh, rtol=1e-12, atol=1e-13)
+    got_h, sm_h = N.pose_graph_optimize(ids, guess, cons)
+    got_d, sm_d = N.pose_graph_optimize(ids, guess, cons, device=0)
+    assert sm_d["termination"] == sm_h["termination"] == 0 and sm_d["iterations"] == sm_h["iterations"]
+    assert sm_d["final_cost"] == pytest.approx(sm_h["final_cost"], rel=1e-9)
+    assert np.allclose(got_d, got_h, rtol=0, atol=1e-8)
+    # reproducible: the device sums have a fixed order
+    cd2, gd2, dd2 = N.pose_graph_linearize(ids, guess, cons, device=0)
+    assert cd2 == cd and np.array_equal(gd2, gd) and np.array_equal(dd2, dd)
+
+
+@pytest.mark.gpu
+def test_sharded_cost_through_the_group():
+    """constraints sharded like the frame pairs that produced them: each shard's cost is reduced on its device and the group
+    adds one double per member (RCCL between GPUs; here one GPU, with and without the RCCL call path)"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, "tests")
+from kcc_helpers import SMALL, nik
+from test_posegraph import make_graph
+N = nik()
+ids, guess, cons = make_graph(120, 4, [(0, 119), (10, 80), (33, 99)])
+whole, _, _ = N.pose_graph_linearize(ids, guess, cons, device=-1)
+g = SMALL
+grp = N.Group.local(N.default_config(rotation_divisor=g["PD"], rotation_channel=g["PC"]), g["H"], g["W"], max_batch=2, max_frames=4, devices=(0,))
+total = 0.0
+for b, e in (N.Group.shard(len(cons), 3, r) for r in range(3)):          # three shards, evaluated one after the other on the one GPU
+    sh = N.PgShard(0, ids, guess, cons[b:e])
+    total += grp.pose_graph_cost([sh])
+    sh.close()
+assert abs(total - whole) <= 1e-12 * whole, (total, whole)
+moved = guess.copy(); moved[5] += [0.01, -0.02, 0.003]
+sh = N.PgShard(0, ids, guess, cons)
+c2 = grp.pose_graph_cost([sh], moved)
+want, _, _ = N.pose_graph_linearize(ids, moved, cons, device=-1)
+assert abs(c2 - want) <= 1e-12 * want and c2 != whole
+sh.close(); grp.close()
+print("PG-GROUP-OK", grp.__class__.__name__)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for force in ("0", "1"):
+        env = dict(os.environ)
+        if force == "1":
+            env["NIK_GROUP_FORCE_RCCL"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0 and "PG-GROUP-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
