@@ -47,7 +47,7 @@ template <int R> __host__ __device__ constexpr int dft_pos(int k) {
 
 // In-register DFT of R points (R = product of base radices).  Output k ends up in v[dft_pos<R>(k)].
 template <int R, bool INV>
-__device__ __forceinline__ void dft_run(float2 (&v)[R]) {
+__device__ __forceinline__ void dft_run(cf2 (&v)[R]) {
     if constexpr (is_base_radix(R)) {
         Radix<R, INV>::run(v);
     } else if constexpr (is_pfa(R)) {
@@ -55,10 +55,10 @@ __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
         // Good-Thomas: input n = (B n1 + A n2) mod R, output k with k = k1 (mod A), k = k2 (mod B):
         //   W_R^(n k) = W_A^(n1 k1) W_B^(n2 k2) -- a plain A x B two-dimensional transform.  All index maps are compile-time
         //   register renames.
-        float2 t[A][B];
+        cf2 t[A][B];
 #pragma unroll
         for (int n2 = 0; n2 < B; ++n2) {
-            float2 c[A];
+            cf2 c[A];
 #pragma unroll
             for (int n1 = 0; n1 < A; ++n1) c[n1] = v[(B * n1 + A * n2) % R];
             dft_run<A, INV>(c);
@@ -76,7 +76,7 @@ __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
         // n = B*n1 + n2, k = k1 + A*k2:  DFT_A over n1, twiddle W_R^(n2*k1), DFT_B over n2
 #pragma unroll
         for (int n2 = 0; n2 < B; ++n2) {
-            float2 t[A];
+            cf2 t[A];
 #pragma unroll
             for (int n1 = 0; n1 < A; ++n1) t[n1] = v[B * n1 + n2];
             dft_run<A, INV>(t);
@@ -88,22 +88,21 @@ __device__ __forceinline__ void dft_run(float2 (&v)[R]) {
 #pragma unroll
             for (int n2 = 1; n2 < B; ++n2) {
                 const int idx = (n2 * k1) % R;
-                float2& x = v[B * k1 + n2];
+                cf2& x = v[B * k1 + n2];
                 if ((4 * idx) % R == 0) {                     // W = (-i)^(4 idx / R): free
                     const int e = ((4 * idx) / R) & 3;
                     const int ee = INV ? ((4 - e) & 3) : e;
-                    if (ee == 1) x = make_float2(x.y, -x.x);
-                    else if (ee == 2) x = make_float2(-x.x, -x.y);
-                    else if (ee == 3) x = make_float2(-x.y, x.x);
+                    if (ee == 1) x = mk2(x.y, -x.x);
+                    else if (ee == 2) x = mk2(-x.x, -x.y);
+                    else if (ee == 3) x = mk2(-x.y, x.x);
                 } else {
-                    const float2 w = make_float2(Wc<R>::c[idx], Wc<R>::s[idx]);
-                    x = INV ? cmulc(x, w) : cmul(x, w);
+                    x = INV ? cmulc_k(x, Wc<R>::c[idx], Wc<R>::s[idx]) : cmul_k(x, Wc<R>::c[idx], Wc<R>::s[idx]);
                 }
             }
         }
 #pragma unroll
         for (int k1 = 0; k1 < A; ++k1) {
-            float2 u[B];
+            cf2 u[B];
 #pragma unroll
             for (int n2 = 0; n2 < B; ++n2) u[n2] = v[B * k1 + n2];
             dft_run<B, INV>(u);
@@ -130,7 +129,7 @@ struct Plan {
     template <bool INV> static constexpr int RM() { return R2_; }                                  // middle (NP==3)
     template <bool INV> static constexpr int RL() { return INV ? R1_ : (NP == 3 ? R3_ : R2_); }   // last radix
     // exchange buffer: index i is stored at i + padc(RF) * (i / RF) (RF = first radix of the direction): the pass-1 writes of
-    // neighbouring threads (stride RF) become stride RF + padc, which is always ODD -- an even stride in float2 puts the 16
+    // neighbouring threads (stride RF) become stride RF + padc, which is always ODD -- an even stride in cf2 puts the 16
     // lanes of a write group on 16 or fewer banks (an odd first radix with one pad element, e.g. the inverse 240 = 15 x 16
     // plan, put all of them on ONE bank pair: 16-way conflicts in every inverse kernel of the 640x480 image family)
     // SWZ plans (240 = 16 x 15): no padding at all.  The radix-16 direction stores index i at i ^ ((i >> 4) & 15) -- its
@@ -216,7 +215,7 @@ template <class P, bool INV> struct Dir {
 };
 
 // Run all passes of one direction on NV independent lines owned by this thread (same j, different data),
-// each with its own exchange buffer ex[v] (LDS, >= P::EXT float2).
+// each with its own exchange buffer ex[v] (LDS, >= P::EXT cf2).
 //   in : vin[v][q]  = x[j + q*MF]          (valid for j < MF)
 //   out: vout[v][q] = X[j + q*ML]          (valid for j < ML), natural order
 // All threads of the workgroup must call this (it contains barriers); the caller must place a barrier
@@ -235,8 +234,8 @@ template <bool WAVE> __device__ __forceinline__ void line_sync() {
     }
 }
 template <class P, bool INV, int NV, bool WAVE = false, int RFV = 0, int RLV = 0>
-__device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)[NV][RLV],
-                                          unsigned j, float2* const (&ex)[NV], const float2* __restrict__ tw) {
+__device__ __forceinline__ void fft_chain(cf2 (&vin)[NV][RFV], cf2 (&vout)[NV][RLV],
+                                          unsigned j, cf2* const (&ex)[NV], const cf2* __restrict__ tw) {
     using D = Dir<P, INV>;
     constexpr int RF = D::RF, RL = D::RL, RM = D::RM;
     static_assert(RFV == RF && RLV == RL, "register arrays must match the plan's first / last radix");
@@ -246,18 +245,18 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
         for (int v = 0; v < NV; ++v) {
             dft_run<RF, INV>(vin[v]);
             if constexpr (D::SWZ) {
-                float2* w = ex[v] + j * 16;
+                cf2* w = ex[v] + j * 16;
                 const unsigned t = j & 15u;
 #pragma unroll
                 for (int q = 0; q < RF; ++q) w[t ^ (unsigned)q] = vin[v][dft_pos<RF>(q)];
             } else if constexpr (D::S3F) {
                 static_assert(RF == 8 && RM == 8 && D::MM == 80 && D::ML == 64, "swizzle constants are the 8 x 8 x 10 plan's");
-                float2* w = ex[v] + j * 8;
+                cf2* w = ex[v] + j * 8;
                 const unsigned t = (j >> 2) & 3u;                // (i >> 5) & 3 for i = 8 j + q
 #pragma unroll
                 for (int q = 0; q < RF; ++q) w[t ^ (unsigned)q] = vin[v][dft_pos<RF>(q)];
             } else {
-                float2* w = ex[v] + j * (RF + D::PADC);
+                cf2* w = ex[v] + j * (RF + D::PADC);
 #pragma unroll
                 for (int q = 0; q < RF; ++q) w[q] = vin[v][dft_pos<RF>(q)];
             }
@@ -266,8 +265,8 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
     if constexpr (P::NP == 3) {
         // ---- pass 2: radix RM, Ns = RF
         constexpr int MM = D::MM;
-        float2 vm[NV][RM];
-        float2 w2[RM];
+        cf2 vm[NV][RM];
+        cf2 w2[RM];
         const unsigned k = j % (unsigned)RF, jb = j / (unsigned)RF;
         const bool act = j < (unsigned)MM;
         if (act) {
@@ -313,10 +312,10 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
         }
     }
     // ---- last pass: radix RL, Ns = N/RL = ML, k = j
-    float2 wl[RL];
+    cf2 wl[RL];
     const bool actl = j < (unsigned)D::ML;
     if (actl) {
-        const float2* t = tw + (P::NP == 3 ? D::OFF3 : 0) + j;
+        const cf2* t = tw + (P::NP == 3 ? D::OFF3 : 0) + j;
 #pragma unroll
         for (int q = 1; q < RL; ++q) wl[q] = t[q * D::ML];
     }
@@ -325,7 +324,7 @@ __device__ __forceinline__ void fft_chain(float2 (&vin)[NV][RFV], float2 (&vout)
         const unsigned pj = D::phys(j);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
-            float2 t[RL];
+            cf2 t[RL];
             if constexpr (D::SWZ) {
                 static_assert(D::ML == 16 && P::NP == 2, "swizzle assumes 16 last-pass butterflies");
 #pragma unroll

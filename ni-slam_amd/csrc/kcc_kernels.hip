@@ -74,7 +74,7 @@ static int ablate_flags() { return 0; }
 #define ABL(a, bit) false
 #endif
 
-// lines per A-type workgroup: 16 float2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
+// lines per A-type workgroup: 16 cf2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
 // use 8 so that twice as many independent workgroups fit in a CU's LDS (their phases overlap better)
 #ifndef KCC_ALX360
 #define KCC_ALX360 8
@@ -333,10 +333,24 @@ enum { EPI_REAL = 0, EPI_KFWD_POLY3 = 1, EPI_ARGMAX = 2, EPI_KFWD_POLYN = 3, EPI
        EPI_ARGMAX_WIN = 6 };   // arg-max restricted to a cyclic window per item (coarse-to-fine registration)
 __host__ __device__ constexpr bool epi_is_kfwd(int e) { return e == EPI_KFWD_POLY3 || e == EPI_KFWD_POLYN || e == EPI_KFWD_GAUSS; }
 
+// kernel-argument pointers to complex data: the C++ interface of this unit (kcc_kernels.h) speaks HIP's float2, the kernels
+// the register-pair type cf2 (kcc_fft.h) -- same memory layout; these wrappers convert at the launch boundary
+struct CP {
+    cf2* p;
+    __host__ __device__ CP() : p(nullptr) {}
+    __host__ __device__ CP(float2* q) : p(reinterpret_cast<cf2*>(q)) {}
+    __host__ __device__ operator cf2*() const { return p; }
+};
+struct CCP {
+    const cf2* p;
+    __host__ __device__ CCP() : p(nullptr) {}
+    __host__ __device__ CCP(const float2* q) : p(reinterpret_cast<const cf2*>(q)) {}
+    __host__ __device__ operator const cf2*() const { return p; }
+};
 struct AArgs {
     int rows, cols, hr, n_items, ablate, rev;
-    const float2* tw_f; const float2* tw_i; const float2* tw_full;
-    const float2* twI_f; const float2* twI_i;                // tables of PlanInv (spectrum-in kernels)
+    CCP tw_f, tw_i, tw_full;
+    CCP twI_f, twI_i;                // tables of PlanInv (spectrum-in kernels)
     // forward source
     const float* src; size_t src_stride; const int* src_idx; int src_pitch;   // image planes: column pitch (>= rows, wrap rows behind)
     const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
@@ -348,7 +362,7 @@ struct AArgs {
     uint8_t* dst8; size_t dst8_stride; int dst8_pitch; const int* dst8_slot;
     float* dbg_plane;                                        // debug tap: the gathered real plane of item 0 (column-major rows x cols)
     // spectrum side
-    float2* spec; size_t spec_stride; size_t plane_stride;
+    CP spec; size_t spec_stride; size_t plane_stride;
     int plane_first, n_planes;                               // kernel_fwd: planes [plane_first, plane_first+n_planes) of each item
     int zz_tiles;                                            // kernel_fwd over (zz, xz): > 0 = only this many column tiles of the zz plane (Hermitian half)
     // inverse outputs
@@ -372,7 +386,7 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
     static constexpr int NPITCH = HH + 1;                // natural-order pitch: odd -> conflict-free transposes
     static constexpr int LDS_ELEMS = LX * (EPITCH > NPITCH ? EPITCH : NPITCH);
-    static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(float2);
+    static constexpr size_t BYTES = (size_t)LDS_ELEMS * sizeof(cf2);
     // Wave-owned LDS regions (wave-local plans, T | 64): wave w holds lines [w LPW, (w+1) LPW).  Their natural-order rows
     // occupy [w LPW NPITCH, (w+1) LPW NPITCH); their exchange buffers are placed INSIDE that range (pitch EPITCH <= NPITCH
     // from the region's start), so between the workgroup-wide load and the workgroup-wide store a wave only ever touches LDS
@@ -380,7 +394,7 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
     // and the waves of a workgroup drift apart instead of marching in lock-step (2 barriers per tile instead of 5 to 7).
     static constexpr int LPW = (64 % T == 0) ? 64 / T : 0;
     static constexpr bool WREG = KCC_WAVE_REGION && KCC_WAVE_LOCAL && LPW > 0 && (LX % (LPW > 0 ? LPW : 1) == 0) && EPITCH <= NPITCH;
-    __device__ static __forceinline__ float2* ex_of(float2* lds, int line) {
+    __device__ static __forceinline__ cf2* ex_of(cf2* lds, int line) {
         if constexpr (WREG) return lds + (line / LPW) * (LPW * NPITCH) + (line % LPW) * EPITCH;
         else return lds + line * EPITCH;
     }
@@ -393,15 +407,15 @@ template <int HH, int LXV, bool INVPLAN> struct ACfg {
 // hand-over between a wave's own natural-order rows and its own exchange buffers (ACfg::WREG), else a workgroup barrier
 template <bool WREG> __device__ __forceinline__ void region_sync() { line_sync<WREG>(); }
 template <int RR>
-__device__ __forceinline__ void zero_fill(float2 (&v)[RR]) {
+__device__ __forceinline__ void zero_fill(cf2 (&v)[RR]) {
 #pragma unroll
-    for (int q = 0; q < RR; ++q) v[q] = make_float2(0.f, 0.f);
+    for (int q = 0; q < RR; ++q) v[q] = mk2(0.f, 0.f);
 }
 // 8-byte load from a 4-byte aligned address (two vertically adjacent taps)
-__device__ __forceinline__ float2 load2(const float* p) {
+__device__ __forceinline__ cf2 load2(const float* p) {
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     const f2u v = *reinterpret_cast<const f2u*>(p);
-    return make_float2(v.x, v.y);
+    return mk2(v.x, v.y);
 }
 // RotateArray (utils.cc:154-161): cv::warpAffine(INTER_LINEAR, BORDER_WRAP).  The fixed-point coordinate
 // terms of OpenCV's WarpAffineInvoker (adelta[c], bdelta[c], X0[r], Y0[r]) are tabulated per candidate angle on
@@ -419,7 +433,7 @@ __device__ __forceinline__ float rot_sample(const float* __restrict__ img, int H
     // Unsigned 32-bit element offsets (masked to 28 bits, a no-op for any real plane, so the byte offset provably
     // fits 32 bits) from the wave-uniform image base: scalar-base + vector-offset loads, no per-lane 64-bit pointers.
     const unsigned oa = (unsigned)(xa * PH + ya) & 0x0FFFFFFFu, ob = (unsigned)(xb * PH + ya) & 0x0FFFFFFFu;
-    const float2 va = load2(img + oa), vb = load2(img + ob);
+    const cf2 va = load2(img + oa), vb = load2(img + ob);
     return bilerp(va.x, vb.x, va.y, vb.y, X & 31, Y & 31);
 }
 #ifndef KCC_FLX360
@@ -452,38 +466,35 @@ template <int HH, int EPI, int LXO = 0> using ICfg = ACfg<HH, (LXO > 0 ? LXO : i
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // All LDS / twiddle reads of a thread are issued before the arithmetic (memory-level parallelism).
 // r2c split of one (k, h-k) pair of one line: Z -> X[k], X[h-k]
-__device__ __forceinline__ void r2c_pair(float2 za, float2 zb, float2 w, float2& xk, float2& xh) {
-    const float2 b = cconj(zb);
-    const float2 e = make_float2(0.5f * (za.x + b.x), 0.5f * (za.y + b.y));
-    const float2 d = make_float2(0.5f * (za.x - b.x), 0.5f * (za.y - b.y));
-    const float2 t = cmul(w, make_float2(d.y, -d.x));                         // w^k * (-i d)
-    xk = cadd(e, t); xh = cconj(csub(e, t));
+__device__ __forceinline__ void r2c_pair(cf2 za, cf2 zb, cf2 w, cf2& xk, cf2& xh) {
+    const cf2 e = scale(cadd_conj(za, zb), 0.5f);                             // (za + conj zb) / 2
+    const cf2 p = cmul(w, scale(csub_conj(za, zb), 0.5f));                    // w^k d,   d = (za - conj zb) / 2
+    xk = sub_ib(e, p);                                                        // e - i w d
+    xh = conj_add_ib(e, p);                                                   // conj(e + i w d)
 }
 // c2r merge of one (k, h-k) pair of one line: X[k], X[h-k] -> Z'[k], Z'[h-k]
-__device__ __forceinline__ void c2r_pair(float2 xa, float2 xb, float2 w, float2& zk, float2& zh) {
-    const float2 b = cconj(xb);
-    const float2 sm = cadd(xa, b), d = csub(xa, b);
-    const float2 u = cmulc(d, w);                                             // conj(w^k) * d
-    const float2 iu = make_float2(-u.y, u.x);
-    zk = cadd(sm, iu); zh = cconj(csub(sm, iu));
+__device__ __forceinline__ void c2r_pair(cf2 xa, cf2 xb, cf2 w, cf2& zk, cf2& zh) {
+    const cf2 sm = cadd_conj(xa, xb), u = cmulc(csub_conj(xa, xb), w);        // xa + conj xb;  conj(w^k) (xa - conj xb)
+    zk = add_ib(sm, u);                                                       // sm + i u
+    zh = conj_sub_ib(sm, u);                                                  // conj(sm - i u)
 }
 
 // natural-order packed-FFT lines in LDS -> r2c split -> transposed global store (k-major spectrum).
 // A thread owns the (k, h-k) pair of TWO adjacent lines: every global access is 16 bytes per lane (8 lanes cover a
 // 128-byte row segment), and all LDS / twiddle reads are issued before the arithmetic.
 template <class C>
-__device__ __forceinline__ void a_post_store(const float2* nat, const float2* __restrict__ tw_full,
-                                             float2* __restrict__ spec, int cols, int x0, int tid) {
+__device__ __forceinline__ void a_post_store(const cf2* nat, const cf2* __restrict__ tw_full,
+                                             cf2* __restrict__ spec, int cols, int x0, int tid) {
     constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
     constexpr int LX2 = C::LX / 2;
     constexpr int TOT = LX2 * NP, ITERS = (TOT + NT - 1) / NT;
-    float2 va[ITERS][2], vb[ITERS][2], w[ITERS];
+    cf2 va[ITERS][2], vb[ITERS][2], w[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
         if (idx < TOT) {
             const int x2 = idx % LX2, k = idx / LX2, kb = k ? HH - k : 0;
-            const float2* L0 = nat + (2 * x2) * NPITCH; const float2* L1 = L0 + NPITCH;
+            const cf2* L0 = nat + (2 * x2) * NPITCH; const cf2* L1 = L0 + NPITCH;
             va[it][0] = L0[k]; va[it][1] = L1[k]; vb[it][0] = L0[kb]; vb[it][1] = L1[kb]; w[it] = tw_full[k];
         }
     }
@@ -494,10 +505,10 @@ __device__ __forceinline__ void a_post_store(const float2* nat, const float2* __
             const int x2 = idx % LX2, k = idx / LX2;
             float4* g = reinterpret_cast<float4*>(spec + x0 + 2 * x2);
             const size_t rk = (size_t)k * cols / 2, rh = (size_t)(HH - k) * cols / 2;      // rows in float4 units
-            float2 xk[2], xh[2];
+            cf2 xk[2], xh[2];
             if (k == 0) {
 #pragma unroll
-                for (int l = 0; l < 2; ++l) { const float2 z = va[it][l]; xk[l] = make_float2(z.x + z.y, 0.f); xh[l] = make_float2(z.x - z.y, 0.f); }
+                for (int l = 0; l < 2; ++l) { const cf2 z = va[it][l]; xk[l] = mk2(z.x + z.y, 0.f); xh[l] = mk2(z.x - z.y, 0.f); }
             } else {
 #pragma unroll
                 for (int l = 0; l < 2; ++l) r2c_pair(va[it][l], vb[it][l], w[it], xk[l], xh[l]);
@@ -510,12 +521,12 @@ __device__ __forceinline__ void a_post_store(const float2* nat, const float2* __
 // transposed global load (k-major spectrum, 16 bytes per lane) -> c2r merge -> natural-order input of the packed
 // inverse FFT in LDS.  All global loads of a thread are issued before the arithmetic.
 template <class C>
-__device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict__ tw_full,
-                                           const float2* __restrict__ spec, int cols, int x0, int tid) {
+__device__ __forceinline__ void a_load_pre(cf2* nat, const cf2* __restrict__ tw_full,
+                                           const cf2* __restrict__ spec, int cols, int x0, int tid) {
     constexpr int HH = C::HALF, NPITCH = C::NPITCH, NT = C::NT, NP = HH / 2 + 1;
     constexpr int LX2 = C::LX / 2;
     constexpr int TOT = LX2 * NP, ITERS = (TOT + NT - 1) / NT;
-    float4 va[ITERS], vb[ITERS]; float2 w[ITERS];
+    float4 va[ITERS], vb[ITERS]; cf2 w[ITERS];
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int idx = tid + it * NT;
@@ -530,14 +541,14 @@ __device__ __forceinline__ void a_load_pre(float2* nat, const float2* __restrict
         const int idx = tid + it * NT;
         if (idx < TOT) {
             const int x2 = idx % LX2, k = idx / LX2;
-            float2* L0 = nat + (2 * x2) * NPITCH; float2* L1 = L0 + NPITCH;
-            const float2 xa[2] = { make_float2(va[it].x, va[it].y), make_float2(va[it].z, va[it].w) };
-            const float2 xb[2] = { make_float2(vb[it].x, vb[it].y), make_float2(vb[it].z, vb[it].w) };
+            cf2* L0 = nat + (2 * x2) * NPITCH; cf2* L1 = L0 + NPITCH;
+            const cf2 xa[2] = { mk2(va[it].x, va[it].y), mk2(va[it].z, va[it].w) };
+            const cf2 xb[2] = { mk2(vb[it].x, vb[it].y), mk2(vb[it].z, vb[it].w) };
             if (k == 0) {                                                     // imag of DC / Nyquist ignored (FFTW c2r)
-                L0[0] = make_float2(xa[0].x + xb[0].x, xa[0].x - xb[0].x);
-                L1[0] = make_float2(xa[1].x + xb[1].x, xa[1].x - xb[1].x);
+                L0[0] = mk2(xa[0].x + xb[0].x, xa[0].x - xb[0].x);
+                L1[0] = mk2(xa[1].x + xb[1].x, xa[1].x - xb[1].x);
             } else {
-                float2 zk[2], zh[2];
+                cf2 zk[2], zh[2];
 #pragma unroll
                 for (int l = 0; l < 2; ++l) c2r_pair(xa[l], xb[l], w[it], zk[l], zh[l]);
                 L0[k] = zk[0]; L1[k] = zk[1];
@@ -594,7 +605,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);   // lines are wave-local: no workgroup barriers inside the chain
     constexpr bool POLAR = (SRC == SRC_POLAR_H || SRC == SRC_POLAR_Q || SRC == SRC_POLAR_T);
-    float2* lds = reinterpret_cast<float2*>(smem);
+    cf2* lds = reinterpret_cast<cf2*>(smem);
     if (ABL(a, 8)) return;
     const int tid = threadIdx.x, line = tid / C::T, j = tid - line * C::T;
     int bx, item;
@@ -610,14 +621,14 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
     }
     const int x0 = bx * A_LX;
 
-    float2 vin[1][D::RF], vout[1][D::RL];
+    cf2 vin[1][D::RF], vout[1][D::RL];
 #ifdef KCC_ABLATE
     zero_fill(vin[0]);
 #endif
     if (SRC == SRC_PLANE) {
         if (j < D::MF) {
             const int pl = a.src_idx ? a.src_idx[item] : item;
-            const float2* src = reinterpret_cast<const float2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.src_pitch);
+            const cf2* src = reinterpret_cast<const cf2*>(a.src + (size_t)pl * a.src_stride + (size_t)(x0 + line) * a.src_pitch);
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) vin[0][q] = src[j + q * D::MF];
         }
@@ -669,10 +680,10 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const unsigned lo = h ? e[qq].z : e[qq].x, hi = h ? e[qq].w : e[qq].y;
-                        const float2 va = load2(ldsf + (lo & 0xFFFFu)), vb = load2(ldsf + hi);   // (sx; sy, sy+1), (sx+1; sy, sy+1)
+                        const cf2 va = load2(ldsf + (lo & 0xFFFFu)), vb = load2(ldsf + hi);   // (sx; sy, sy+1), (sx+1; sy, sy+1)
                         r[h] = bilerp(va.x, vb.x, va.y, vb.y, (lo >> 16) & 31, (lo >> 21) & 31);
                     }
-                    vin[0][seg * QS + qq] = make_float2(r[0], r[1]);
+                    vin[0][seg * QS + qq] = mk2(r[0], r[1]);
                 }
             }
         }
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
             for (int q = 0; q < D::RF; ++q) {
                 const int m = j + q * D::MF;
                 const int2 xr = X0[m], yr = Y0[m];
-                vin[0][q] = make_float2(rot_sample(img, a.rows, a.src_pitch, a.cols, ad, bd, xr.x, yr.x),
+                vin[0][q] = mk2(rot_sample(img, a.rows, a.src_pitch, a.cols, ad, bd, xr.x, yr.x),
                                         rot_sample(img, a.rows, a.src_pitch, a.cols, ad, bd, xr.y, yr.y));
                 // cap the number of gathers in flight (register pressure -> occupancy): no hoisting across groups
                 if ((q % KCC_GATHER_GROUP) == KCC_GATHER_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
@@ -776,17 +787,17 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
                     const uint8_t* t = box + (Y >> 5) * R::PITCH + (X >> 5);
                     r[h] = bilerp(unit_u8(t[0]), unit_u8(t[1]), unit_u8(t[R::PITCH]), unit_u8(t[R::PITCH + 1]), X & 31, Y & 31);
                 }
-                vin[0][q] = make_float2(r[0], r[1]);
+                vin[0][q] = mk2(r[0], r[1]);
             }
         }
         __syncthreads();                                     // boxes consumed before the exchange buffer is written
     }
     if (a.dbg_plane && j < D::MF) {                          // debug tap: what the gather produced (tests: bit-exact vs the oracle)
-        float2* o = reinterpret_cast<float2*>(a.dbg_plane + ((size_t)item * a.cols + x0 + line) * (size_t)(2 * HH));
+        cf2* o = reinterpret_cast<cf2*>(a.dbg_plane + ((size_t)item * a.cols + x0 + line) * (size_t)(2 * HH));
 #pragma unroll
         for (int q = 0; q < D::RF; ++q) o[j + q * D::MF] = vin[0][q];
     }
-    float2* const ex[1] = { C::ex_of(lds, line) };
+    cf2* const ex[1] = { C::ex_of(lds, line) };
     if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, a.tw_f);
     region_sync<C::WREG>();                                  // exchange buffer fully consumed
     if (j < D::ML) {
@@ -818,7 +829,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
     using C = FCfg<HH>; using P = typename C::P; using D = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
     constexpr int A_LX = C::LX, ROWS = 2 * HH, NR = (ROWS + C::NT - 1) / C::NT;
-    float2* lds = reinterpret_cast<float2*>(smem);
+    cf2* lds = reinterpret_cast<cf2*>(smem);
     if (ABL(a, 8)) return;
     int g, item;
     xcd_coords((a.cols / A_LX) / tpw, a.n_items, g, item, a.rev);           // groups of tpw tiles; an image's groups share an XCD
@@ -840,7 +851,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
         // re-read: hoisted out of the loop (which the compiler does eagerly) those values sit in ~60 VGPRs for the loop's
         // whole length and push the kernel into scratch spills.
         int tid = threadIdx.x;
-        const float2* tw_f = a.tw_f; const float2* tw_full = a.tw_full;
+        const cf2* tw_f = a.tw_f; const cf2* tw_full = a.tw_full;
         asm volatile("" : "+v"(tid), "+s"(tw_f), "+s"(tw_full));
         const int line = tid / C::T, j = tid - line * C::T;
         if (t + 1 < tpw) fetch(nxt, x0 + A_LX, tid);
@@ -857,17 +868,17 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
             }
         }
         __syncthreads();
-        float2 vin[1][D::RF], vout[1][D::RL];
+        cf2 vin[1][D::RF], vout[1][D::RL];
         if (j < D::MF) {
             const uint8_t* sb = reinterpret_cast<const uint8_t*>(smem) + line;
 #pragma unroll
             for (int q = 0; q < D::RF; ++q) {
                 const int m = j + q * D::MF;
-                vin[0][q] = make_float2(unit_u8(sb[32 * m]), unit_u8(sb[32 * m + 16]));
+                vin[0][q] = mk2(unit_u8(sb[32 * m]), unit_u8(sb[32 * m + 16]));
             }
         }
         __syncthreads();                                     // staged rows consumed before the exchange overwrites them
-        float2* const ex[1] = { C::ex_of(lds, line) };
+        cf2* const ex[1] = { C::ex_of(lds, line) };
         if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vin, vout, j, ex, tw_f);
         region_sync<C::WREG>();                              // exchange buffer fully consumed
         if (j < D::ML) {
@@ -896,7 +907,7 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
     using C = ICfg<HH, EPI, LXO>; using P = typename C::P; using DI = Dir<P, true>; using DF = Dir<P, false>;
     constexpr bool WL = KCC_WAVE_LOCAL && (64 % C::T == 0);
     constexpr int NW = (C::NT + 63) / 64;
-    float2* lds = reinterpret_cast<float2*>(smem);
+    cf2* lds = reinterpret_cast<cf2*>(smem);
     if (ABL(a, 8)) return;
     __shared__ float red_f[NW];
     __shared__ int red_i[NW];
@@ -926,17 +937,17 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
         plane = KFWD ? a.plane_first + item2 % a.n_planes : 0;
     }
     const int x0 = bx * A_LX;
-    float2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
+    cf2* spec = a.spec + (size_t)item * a.spec_stride + (size_t)plane * a.plane_stride;
 
     if (!ABL(a, 1)) a_load_pre<C>(lds, a.tw_full, spec, a.cols, x0, tid);
     __syncthreads();
-    float2 vin[1][DI::RF], vout[1][DI::RL];
+    cf2 vin[1][DI::RF], vout[1][DI::RL];
     if (j < DI::MF) {
 #pragma unroll
         for (int q = 0; q < DI::RF; ++q) vin[0][q] = lds[line * C::NPITCH + j + q * DI::MF];
     }
     region_sync<C::WREG>();                                  // natural buffer consumed before the exchange overwrites it
-    float2* const ex[1] = { C::ex_of(lds, line) };
+    cf2* const ex[1] = { C::ex_of(lds, line) };
     if (!ABL(a, 4)) fft_chain<P, true, 1, WL>(vin, vout, j, ex, a.tw_i);
     const float size = (float)((long)a.rows * a.cols);       // IFFT: x / x.size()  (correlation_flow.cc:76)
     const float rsize = 1.0f / size;                          // (applied as a multiplication: 1 ulp, far below FFT rounding)
@@ -965,7 +976,7 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
                 const int ys = r >= HQ ? r - HQ : r + HQ;
                 const float v0 = vout[0][q].x * rsize, v1 = vout[0][q].y * rsize;
                 if (HQ & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
-                else *reinterpret_cast<float2*>(col + ys) = make_float2(v0, v1);
+                else *reinterpret_cast<cf2*>(col + ys) = mk2(v0, v1);
                 if (mirror) {
                     // rows -r and -(r+1) sit at y0 = (HQ - r) mod H and y0 - 1: neighbours in memory except across the
                     // cyclic seam (r == HQ), so one 8-byte store
@@ -977,9 +988,9 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
         }
     } else if (EPI == EPI_REAL) {
         if (j < DI::ML) {
-            float2* dst = reinterpret_cast<float2*>(a.real_out + (size_t)item * a.real_stride + (size_t)(x0 + line) * a.rows);
+            cf2* dst = reinterpret_cast<cf2*>(a.real_out + (size_t)item * a.real_stride + (size_t)(x0 + line) * a.rows);
 #pragma unroll
-            for (int q = 0; q < DI::RL; ++q) dst[j + q * DI::ML] = make_float2(vout[0][q].x * rsize, vout[0][q].y * rsize);
+            for (int q = 0; q < DI::RL; ++q) dst[j + q * DI::ML] = mk2(vout[0][q].x * rsize, vout[0][q].y * rsize);
         }
     } else if (KFWD) {
         static_assert(DI::RL == DF::RF && DI::ML == DF::MF, "inverse output layout must equal forward input layout");
@@ -996,7 +1007,7 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
                 const float k0 = kernel_value<KT>(a.fn, vout[0][q].x * rsize, gbias, gscale);
                 const float k1 = kernel_value<KT>(a.fn, vout[0][q].y * rsize, gbias, gscale);
                 mx = fmaxf(mx, fmaxf(fabsf(k0), fabsf(k1)));
-                vout[0][q] = make_float2(k0, k1);
+                vout[0][q] = mk2(k0, k1);
             }
         }
         for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -1004,7 +1015,7 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
         // a plain store, no atomic and no workgroup rendezvous; the ridge solve folds the parts (parts_max)
         if ((tid & 63) == 0) a.maxbuf[(size_t)(2 * item + plane) * KCC_MAXPARTS + bx * NW + (tid >> 6)] = __float_as_uint(mx);
         region_sync<C::WREG>();                              // exchange buffer consumed before the forward chain
-        float2 fout[1][DF::RL];
+        cf2 fout[1][DF::RL];
         if (!ABL(a, 4)) fft_chain<P, false, 1, WL>(vout, fout, j, ex, a.tw_f);
         region_sync<C::WREG>();
         if (j < DF::ML) {
@@ -1271,18 +1282,18 @@ enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_I
 
 struct BArgs {
     int cols, hr, ablate, rev;
-    const float2* tw_f; const float2* tw_i;
-    const float2* src; size_t src_stride; const int* src_idx;     // primary input
-    const float2* zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
+    CCP tw_f, tw_i;
+    CCP src; size_t src_stride; const int* src_idx;     // primary input
+    CCP zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
     size_t in_plane_stride;                                       // SOLVE: plane 1 offset inside src item
-    float2* dst; size_t dst_stride; const int* dst_slot;          // primary output
-    float2* dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
+    CP dst; size_t dst_stride; const int* dst_slot;          // primary output
+    CP dst2; size_t dst2_stride; const int* dst2_slot;       // secondary output (FWD_MUL_INV*: the forward spectrum X itself)
     size_t out_plane_stride;                                      // MUL_INV: plane 1 offset inside dst item
     const unsigned* maxbuf; int n_parts[2]; float lambda;     // running-max parts of the kernel planes (see kA_inv kernel_fwd)
     int zz_half;                                                  // SOLVE_INV: plane 0 holds only the columns <= N/2 (Hermitian);
                                                                   // (FWD_)MUL_INV: > 0 = number of zz-plane columns to store
     unsigned* maxbuf_zero;                                        // MUL_INV: running-max slots to reset for the next stage
-    const float2* kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
+    CCP kzz; size_t kzz_stride; const unsigned* mzz;   // SOLVE_CACHED: per-slot Kzz spectra and max (slot = z_idx[item])
 };
 
 // lines per workgroup: fewer for the modes that hold two planes' exchange buffers (LDS-limited occupancy)
@@ -1323,11 +1334,11 @@ template <int N, int MODE> struct BCfg {
                                                         : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
     static constexpr int NT = LK * T;
     static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
-    static constexpr size_t BYTES = (size_t)NV * LK * EPITCH * sizeof(float2);
+    static constexpr size_t BYTES = (size_t)NV * LK * EPITCH * sizeof(cf2);
 };
 
 template <int RR>
-__device__ __forceinline__ void load_strided(float2 (&v)[RR], const float2* __restrict__ p, int stride, bool ok) {
+__device__ __forceinline__ void load_strided(cf2 (&v)[RR], const cf2* __restrict__ p, int stride, bool ok) {
     if (ok) {
 #pragma unroll
         for (int q = 0; q < RR; ++q) v[q] = p[q * stride];
@@ -1336,7 +1347,7 @@ __device__ __forceinline__ void load_strided(float2 (&v)[RR], const float2* __re
     }
 }
 template <int RR>
-__device__ __forceinline__ void store_strided(const float2 (&v)[RR], float2* __restrict__ p, int stride) {
+__device__ __forceinline__ void store_strided(const cf2 (&v)[RR], cf2* __restrict__ p, int stride) {
 #pragma unroll
     for (int q = 0; q < RR; ++q) p[q * stride] = v[q];
 }
@@ -1354,7 +1365,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using C = BCfg<N, MODE>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
     static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
-    float2* lds = reinterpret_cast<float2*>(smem);
+    cf2* lds = reinterpret_cast<cf2*>(smem);
     __shared__ float s_rmax[2];
     if (ABL(a, 8)) return;
     const unsigned tid = threadIdx.x, lk = tid / (unsigned)C::T, j = tid - lk * C::T;
@@ -1365,30 +1376,30 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     const bool nofft = ABL(a, 4);
     const size_t loff = (size_t)k * N + j;
     constexpr int NVM = C::NV;
-    float2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
-    float2* const ex2[2] = { lds + (NVM * lk) * C::EPITCH, lds + (NVM * lk + NVM - 1) * C::EPITCH };
+    cf2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
+    cf2* const ex2[2] = { lds + (NVM * lk) * C::EPITCH, lds + (NVM * lk + NVM - 1) * C::EPITCH };
 
     if (MODE == B_FWD || MODE == B_INV) {
         constexpr bool INV = (MODE == B_INV);
         using D = Dir<P, INV>;
-        float2 vin[1][D::RF], vout[1][D::RL];
+        cf2 vin[1][D::RF], vout[1][D::RL];
         load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, D::MF, valid && j < D::MF);
         if (!nofft) fft_chain<P, INV, 1>(vin, vout, j, ex1, INV ? a.tw_i : a.tw_f);
         if (vst && j < D::ML)
             store_strided(vout[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, D::ML);
     } else if (MODE == B_FWD_ABS_INV) {
         // fft_result = FFT(image);  IFFT(fft_result.abs())   (correlation_flow.cc:91-92)
-        float2 vin[1][DF::RF], f[1][DF::RL], o[1][DI::RL];
+        cf2 vin[1][DF::RF], f[1][DF::RL], o[1][DI::RL];
         load_strided(vin[0], a.src + (size_t)item * a.src_stride + loff, DF::MF, valid && j < DF::MF);
         if (!nofft) fft_chain<P, false, 1>(vin, f, j, ex1, a.tw_f);
         if (vst && j < DF::ML)
             store_strided(f[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, DF::ML);
 #pragma unroll
-        for (int q = 0; q < DF::RL; ++q) f[0][q] = make_float2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
+        for (int q = 0; q < DF::RL; ++q) f[0][q] = mk2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
         __syncthreads();
         if (!nofft) fft_chain<P, true, 1>(f, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) {
-            float2* d2 = a.dst2 + (size_t)item * a.dst2_stride + loff;
+            cf2* d2 = a.dst2 + (size_t)item * a.dst2_stride + loff;
             if (a.zz_half > 0) {                              // only the columns the even-half inverse row pass reads
 #pragma unroll
                 for (int q = 0; q < DI::RL; ++q) if ((int)j + q * DI::ML < a.zz_half) d2[q * DI::ML] = o[0][q];
@@ -1398,11 +1409,11 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
     } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
         // xzf = xf * zf.conjugate() for (z,z) and (x,z)   (correlation_flow.cc:210-211,220-221)
-        float2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
+        cf2 pr[2][DI::RF], o[2][DI::RL], zv[DI::RF];
         // the key spectrum line is needed only after the forward chain: issue its loads first (latency hidden)
         load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
         if (MODE == B_FWD_MUL_INV) {
-            float2 vin[1][DF::RF], x[1][DF::RL];
+            cf2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
             if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
             if (a.dst2 && vst && j < DF::ML)                 // X is a result of its own (the frame's spectrum): keep it
@@ -1411,17 +1422,17 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(x[0][q], zv[q]);
             __syncthreads();
         } else {
-            float2 xv[DI::RF];
+            cf2 xv[DI::RF];
             load_strided(xv, a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DI::MF, valid && j < DI::MF);
 #pragma unroll
             for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(xv[q], zv[q]);
         }
 #pragma unroll
-        for (int q = 0; q < DI::RF; ++q) pr[0][q] = make_float2(zv[q].x * zv[q].x + zv[q].y * zv[q].y, 0.f);
+        for (int q = 0; q < DI::RF; ++q) pr[0][q] = mk2(zv[q].x * zv[q].x + zv[q].y * zv[q].y, 0.f);
         if (!nofft) {
             if (C::SEQ) {
-                float2 (&p0)[1][DI::RF] = reinterpret_cast<float2 (&)[1][DI::RF]>(pr[0]); float2 (&p1)[1][DI::RF] = reinterpret_cast<float2 (&)[1][DI::RF]>(pr[1]);
-                float2 (&o0)[1][DI::RL] = reinterpret_cast<float2 (&)[1][DI::RL]>(o[0]);  float2 (&o1)[1][DI::RL] = reinterpret_cast<float2 (&)[1][DI::RL]>(o[1]);
+                cf2 (&p0)[1][DI::RF] = reinterpret_cast<cf2 (&)[1][DI::RF]>(pr[0]); cf2 (&p1)[1][DI::RF] = reinterpret_cast<cf2 (&)[1][DI::RF]>(pr[1]);
+                cf2 (&o0)[1][DI::RL] = reinterpret_cast<cf2 (&)[1][DI::RL]>(o[0]);  cf2 (&o1)[1][DI::RL] = reinterpret_cast<cf2 (&)[1][DI::RL]>(o[1]);
                 fft_chain<P, true, 1>(p0, o0, j, ex1, a.tw_i);
                 __syncthreads();
                 fft_chain<P, true, 1>(p1, o1, j, ex1, a.tw_i);
@@ -1430,7 +1441,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             }
         }
         if (vst && j < DI::ML) {
-            float2* d = a.dst + (size_t)item * a.dst_stride + loff;
+            cf2* d = a.dst + (size_t)item * a.dst_stride + loff;
             if (a.zz_half > 0) {
                 // only the columns the Hermitian-half kernel_fwd reads (x < zz_half) of the zz plane are kept
 #pragma unroll
@@ -1442,18 +1453,18 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
     } else if (MODE == B_ZZ_INV) {
         // Kzz half of the kernel stage: |Z|^2 -> inverse col FFT (plane 0)
-        float2 zv[1][DI::RF], o[1][DI::RL];
+        cf2 zv[1][DI::RF], o[1][DI::RL];
         load_strided(zv[0], a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
 #pragma unroll
-        for (int q = 0; q < DI::RF; ++q) zv[0][q] = make_float2(zv[0][q].x * zv[0][q].x + zv[0][q].y * zv[0][q].y, 0.f);
+        for (int q = 0; q < DI::RF; ++q) zv[0][q] = mk2(zv[0][q].x * zv[0][q].x + zv[0][q].y * zv[0][q].y, 0.f);
         if (!nofft) fft_chain<P, true, 1>(zv, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     } else if (MODE == B_MUL_INV_X || MODE == B_FWD_MUL_INV_X) {
         // Kxz half: X conj Z -> inverse col FFT (plane 1)
-        float2 pr[1][DI::RF], o[1][DI::RL], zv[DI::RF];
+        cf2 pr[1][DI::RF], o[1][DI::RL], zv[DI::RF];
         load_strided(zv, a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
         if (MODE == B_FWD_MUL_INV_X) {
-            float2 vin[1][DF::RF], x[1][DF::RL];
+            cf2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
             if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
             if (a.dst2 && vst && j < DF::ML)
@@ -1462,7 +1473,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(x[0][q], zv[q]);
             __syncthreads();
         } else {
-            float2 xv[DI::RF];
+            cf2 xv[DI::RF];
             load_strided(xv, a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DI::MF, valid && j < DI::MF);
 #pragma unroll
             for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(xv[q], zv[q]);
@@ -1471,7 +1482,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + a.out_plane_stride + loff, DI::ML);
     } else if (MODE == B_SOLVE_CACHED) {
         // as SOLVE_INV, but Kzz (already transformed) and its max come from the key slot's cache
-        float2 vin[1][DF::RF], kx[1][DF::RL], kz[DF::RL], g[1][DI::RF], o[1][DI::RL];
+        cf2 vin[1][DF::RF], kx[1][DF::RL], kz[DF::RL], g[1][DI::RF], o[1][DI::RL];
         const int zslot = a.z_idx[item];
         load_strided(vin[0], a.src + (size_t)item * a.src_stride + a.in_plane_stride + loff, DF::MF, valid && j < DF::MF);
         load_strided(kz, a.kzz + (size_t)zslot * a.kzz_stride + loff, DF::ML, valid && j < DF::ML);
@@ -1484,11 +1495,11 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
         for (int q = 0; q < DF::RL; ++q) {
-            const float2 den = make_float2(kz[q].x * rzz + a.lambda, kz[q].y * rzz);
-            const float2 num = make_float2(kx[0][q].x * rxz, kx[0][q].y * rxz);
+            const cf2 den = mk2(kz[q].x * rzz + a.lambda, kz[q].y * rzz);
+            const cf2 num = mk2(kx[0][q].x * rxz, kx[0][q].y * rxz);
             const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
-            const float2 gg = cmulc(num, den);
-            g[0][q] = make_float2(gg.x * inv, gg.y * inv);
+            const cf2 gg = cmulc(num, den);
+            g[0][q] = mk2(gg.x * inv, gg.y * inv);
         }
         if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
         __syncthreads();
@@ -1496,17 +1507,17 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     } else {
         // H = T/(Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l)
-        float2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
-        const float2* src = a.src + (size_t)item * a.src_stride + loff;
+        cf2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
+        const cf2* src = a.src + (size_t)item * a.src_stride + loff;
         if (a.zz_half) {
             // plane 0 (the Kzz kernel plane after its row pass) is Hermitian along x: element x > N/2 = conj(element N - x)
             if (valid && j < DF::MF) {
-                const float2* row = a.src + (size_t)item * a.src_stride + (size_t)k * N;
+                const cf2* row = a.src + (size_t)item * a.src_stride + (size_t)k * N;
 #pragma unroll
                 for (int q = 0; q < DF::RF; ++q) {
                     const int x = (int)j + q * DF::MF;
-                    const float2 v = row[x <= N / 2 ? x : N - x];
-                    vin[0][q] = make_float2(v.x, x <= N / 2 ? v.y : -v.y);
+                    const cf2 v = row[x <= N / 2 ? x : N - x];
+                    vin[0][q] = mk2(v.x, x <= N / 2 ? v.y : -v.y);
                 }
             } else {
                 zero_fill(vin[0]);
@@ -1523,8 +1534,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
         if (!nofft) {
             if (C::SEQ) {
-                float2 (&v0)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[0]); float2 (&v1)[1][DF::RF] = reinterpret_cast<float2 (&)[1][DF::RF]>(vin[1]);
-                float2 (&k0)[1][DF::RL] = reinterpret_cast<float2 (&)[1][DF::RL]>(kk[0]);  float2 (&k1)[1][DF::RL] = reinterpret_cast<float2 (&)[1][DF::RL]>(kk[1]);
+                cf2 (&v0)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[0]); cf2 (&v1)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[1]);
+                cf2 (&k0)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[0]);  cf2 (&k1)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[1]);
                 fft_chain<P, false, 1>(v0, k0, j, ex1, a.tw_f);
                 __syncthreads();
                 fft_chain<P, false, 1>(v1, k1, j, ex1, a.tw_f);
@@ -1538,11 +1549,11 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
         for (int q = 0; q < DF::RL; ++q) {
-            const float2 den = make_float2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
-            const float2 num = make_float2(kk[1][q].x * rxz, kk[1][q].y * rxz);
+            const cf2 den = mk2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
+            const cf2 num = mk2(kk[1][q].x * rxz, kk[1][q].y * rxz);
             const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
-            const float2 gg = cmulc(num, den);
-            g[0][q] = make_float2(gg.x * inv, gg.y * inv);
+            const cf2 gg = cmulc(num, den);
+            g[0][q] = mk2(gg.x * inv, gg.y * inv);
         }
         if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
         __syncthreads();
@@ -1691,14 +1702,14 @@ void launch_B_solve_inv(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 // ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
-__global__ void k_energy(const float2* __restrict__ xsrc, size_t x_stride, const int* x_idx,
-                         const float2* __restrict__ zsrc, size_t z_stride, const int* z_idx, size_t n, float* energy) {
+__global__ void k_energy(CCP xsrc, size_t x_stride, const int* x_idx,
+                         CCP zsrc, size_t z_stride, const int* z_idx, size_t n, float* energy) {
     __shared__ double red[256];
     const int item = blockIdx.x, which = blockIdx.y, tid = threadIdx.x;
-    const float2* p = which == 0 ? xsrc + (size_t)(x_idx ? x_idx[item] : item) * x_stride
+    const cf2* p = which == 0 ? xsrc + (size_t)(x_idx ? x_idx[item] : item) * x_stride
                                  : zsrc + (size_t)(z_idx ? z_idx[item] : item) * z_stride;
     double acc = 0.0;
-    for (size_t i = tid; i < n; i += 256) { const float2 v = p[i]; acc += (double)(v.x * v.x + v.y * v.y); }
+    for (size_t i = tid; i < n; i += 256) { const cf2 v = p[i]; acc += (double)(v.x * v.x + v.y * v.y); }
     red[tid] = acc;
     __syncthreads();
     for (int s = 128; s >= 1; s >>= 1) { if (tid < s) red[tid] += red[tid + s]; __syncthreads(); }
@@ -1706,7 +1717,7 @@ __global__ void k_energy(const float2* __restrict__ xsrc, size_t x_stride, const
 }
 void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, size_t x_stride, const int* x_idx,
                    const float2* zsrc, size_t z_stride, const int* z_idx, float* energy) {
-    hipLaunchKernelGGL(k_energy, dim3(n_items, 2), dim3(256), 0, s, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx,
+    hipLaunchKernelGGL(k_energy, dim3(n_items, 2), dim3(256), 0, s, CCP(xsrc), x_stride, x_idx, CCP(zsrc), z_stride, z_idx,
                        (size_t)g.hr * g.cols, energy);
 }
 
@@ -1831,8 +1842,8 @@ void launch_make_shifted(hipStream_t s, const float* p, float* S, int H, int W) 
     hipLaunchKernelGGL(k_make_shifted, dim3((H * W + 255) / 256), dim3(256), 0, s, p, S, H, W);
 }
 
-__global__ void k_transpose_c(const float2* __restrict__ src, float2* __restrict__ dst, int R, int C) {
-    __shared__ float2 tile[32][33];
+__global__ void k_transpose_c(CCP src, CP dst, int R, int C) {
+    __shared__ cf2 tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
         const int r = r0 + j, c = c0 + threadIdx.x;
@@ -1846,7 +1857,7 @@ __global__ void k_transpose_c(const float2* __restrict__ src, float2* __restrict
 }
 void launch_transpose_c(hipStream_t s, const float2* src, float2* dst, int src_rows, int src_cols) {
     dim3 grid((src_cols + 31) / 32, (src_rows + 31) / 32), block(32, 8);
-    hipLaunchKernelGGL(k_transpose_c, grid, block, 0, s, src, dst, src_rows, src_cols);
+    hipLaunchKernelGGL(k_transpose_c, grid, block, 0, s, CCP(src), CP(dst), src_rows, src_cols);
 }
 
 }  // namespace kcc

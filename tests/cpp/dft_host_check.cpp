@@ -11,8 +11,8 @@
 using namespace kcc;
 
 template <int R, bool INV> double check() {
-    float2 v[R]; std::complex<double> in[R];
-    for (int i = 0; i < R; ++i) { v[i] = make_float2((float)sin(1.0 + 3.7 * i), (float)cos(0.3 + 1.9 * i * i)); in[i] = { v[i].x, v[i].y }; }
+    cf2 v[R]; std::complex<double> in[R];
+    for (int i = 0; i < R; ++i) { v[i] = mk2((float)sin(1.0 + 3.7 * i), (float)cos(0.3 + 1.9 * i * i)); in[i] = { v[i].x, v[i].y }; }
     dft_run<R, INV>(v);
     double worst = 0;
     bool used[R] = {};
