@@ -58,7 +58,7 @@ def _profile(cf, run_once, steps):
         run_once()
     st = cf.profile_read()
     cf.profile_enable(False)
-    cf.set_streams(int(os.environ.get("NIK_STREAMS", "2")))
+    cf.set_streams(int(os.environ.get("NIK_STREAMS", "3")))
     tot = sum(s["ms"] for s in st) or 1.0
     kernels = []
     for s in sorted(st, key=lambda s: -s["ms"]):
@@ -143,7 +143,7 @@ def _line(metric, unit, value, world, args, ms_per_step, workload, bytes_per_uni
     out = {"metric": metric, "value": round(value, 1), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
            "data": "synthetic",
-           "config": dict({"workload": workload, "streams_per_gpu": int(os.environ.get("NIK_STREAMS", "2"))}, **(extra_cfg or {})),
+           "config": dict({"workload": workload, "streams_per_gpu": int(os.environ.get("NIK_STREAMS", "3"))}, **(extra_cfg or {})),
            "path_roofline": {"bytes_per_unit": bytes_per_unit, "achieved_GBps": round(value / world * bytes_per_unit / 1e9, 1),
                              "frac_of_8TBps": round(value / world * bytes_per_unit / HBM_PEAK, 4)}}
     out.update(more)

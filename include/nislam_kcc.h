@@ -83,7 +83,7 @@ int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
 /* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
 int   nik_device(const nik_ctx* ctx);                        /* HIP device ordinal the context lives on */
-/* A batched call is split over up to `n` concurrent HIP streams ("lanes", default 2 or $NIK_STREAMS, max 4);
+/* A batched call is split over up to `n` concurrent HIP streams ("lanes", default 3 or $NIK_STREAMS, max 4);
  * returns the number now active.  Outputs do not depend on it. */
 int  nik_set_streams(nik_ctx* ctx, int n);
 /* A batched call of more than streams * `pairs` pairs is cut into chunks of at most `pairs` pairs, dealt to the streams in
