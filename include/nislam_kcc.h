@@ -355,6 +355,9 @@ int  nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses /* NULL: unchang
  * types[i]: 0 = KCC edge between consecutive keyframes, 1 = loop edge), and how often CheckAndOptimize has optimised */
 int  nik_tracker_edges(const nik_tracker* t, nik_pg_constraint* out, int32_t* types, int cap, int* n);
 int  nik_tracker_optimizations(const nik_tracker* t, nik_pg_summary* last /* may be NULL */);
+/* nik_tracker_push_dev registers, in the batch that serves the current keyframe, also the frames behind the frames it GUESSES to
+ * become the next keyframes (regular spacing); out = [guesses that held, guesses that failed, batched pose calls so far] */
+int  nik_tracker_speculation(const nik_tracker* t, long out[3]);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

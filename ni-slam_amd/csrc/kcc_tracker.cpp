@@ -50,6 +50,9 @@ struct nik_tracker {
     std::vector<nik_frame> free_slots;
     std::vector<nik_frame> keyframes;
     int spec_depth = 8;                      // frames registered speculatively per batch (adapts to the keyframe spacing)
+    int last_gap = 0;                        // frames between the last two keyframes (0: unknown yet)
+    int spec_chain = 0;                      // further key segments registered in the same batch against GUESSED keyframes
+    long spec_hits = 0, spec_misses = 0, gpu_calls = 0;      // diagnostics (nik_tracker_speculation)
     nik_map* map = nullptr;                  // optional (borrowed): keyframes are added to it and searched for loops
     int to_find_loop = 0;
     // MapBuilder::_loop_matches: loops found at CONSECUTIVE keyframes; a keyframe without a loop triggers CheckAndOptimize
@@ -264,6 +267,13 @@ int nik_tracker_loops(const nik_tracker* t, nik_loop_result* out, int cap, int* 
 
 int nik_tracker_pending_loops(const nik_tracker* t) { return t ? (int)t->loops.size() : 0; }
 
+// diagnostics of the key-frame chain speculation of nik_tracker_push_dev: [guesses that held, guesses that failed, batched pose calls]
+int nik_tracker_speculation(const nik_tracker* t, long out[3]) {
+    if (!t || !out) return NIK_ERR_INVALID_ARG;
+    out[0] = t->spec_hits; out[1] = t->spec_misses; out[2] = t->gpu_calls;
+    return NIK_OK;
+}
+
 int nik_tracker_poses(const nik_tracker* t, int32_t* frame_ids, double* poses, int cap, int* n) {
     if (!t || !n) return NIK_ERR_INVALID_ARG;
     *n = (int)t->kf_ids.size();
@@ -308,8 +318,8 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     if ((int)t->free_slots.size() < n) return NIK_ERR_CAPACITY;
     std::vector<nik_frame> slot(n);
     for (int i = 0; i < n; ++i) { slot[i] = t->free_slots.back(); t->free_slots.pop_back(); }
-    std::vector<nik_pose_result> res(n);
-    std::vector<nik_frame> keys(n);
+    std::vector<nik_pose_result> res(t->max_batch);          // (a batch may hold a frame more than once: once per key segment)
+    std::vector<nik_frame> keys(t->max_batch);
     int rc, start = 0;
     memset(out, 0, sizeof(out[0]) * (size_t)n);
     // on an error: frames that did not become keyframes give their slots back; outputs of unprocessed frames stay zero
@@ -317,18 +327,61 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     // the spectra of a frame do not depend on the keyframe: all n frames in one batch
     if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return bail(rc);
     if (!t->init) { first_frame(t, slot[0], out[0]); start = 1; }
+    struct Seg { int key_idx, first, count, res_off; };             // key_idx: index into this push (-1: the current keyframe)
+    std::vector<Seg> segs;
+    std::vector<nik_frame> curs(t->max_batch);
     while (start < n) {
         // Register the next `depth` frames against the current keyframe in one batch.  The registrations are
         // speculative: they are valid up to and including the next inserted frame, the ones after it are redone
         // against the new keyframe.  The depth follows the observed keyframe spacing (twice the last gap), so
         // little work is thrown away while the batches stay as large as the sequence allows.
-        const int m = std::min(n - start, std::max(1, t->spec_depth));
-        for (int i = 0; i < m; ++i) keys[i] = t->key_slot;
-        if ((rc = nik_pose_batch(t->ctx, m, keys.data(), slot.data() + start, 1, res.data()))) return bail(rc);
-        int i = 0; bool inserted = false;
-        while (i < m && !inserted) { inserted = apply_result(t, res[i], slot[start + i], out[start + i]); ++i; }
-        t->spec_depth = inserted ? std::min(t->max_batch, std::max(4, 2 * i)) : std::min(t->max_batch, 2 * std::max(1, t->spec_depth));
-        start += i;
+        //
+        // Key-frame chains.  Every keyframe switch would otherwise cost one host round trip of a small, latency-bound batch
+        // (~0.1 ms whatever its size below 16 pairs).  When the spacing has been regular (gap g), the frame that becomes the
+        // next keyframe is probably frame start + g - 1: the SAME batch therefore also registers the frames behind that
+        // guess against it (every frame's spectra are resident: any frame can serve as a key), and so on for up to
+        // spec_chain further guesses.  A guess that turns out right saves the round trip; a wrong one costs its few pairs of
+        // GPU work.  Outputs are exactly those of sequential calls: a speculative result is used only if its key is the
+        // frame the reference's rule really inserted.
+        segs.clear();
+        int total = 0;
+        const int depth = std::max(1, t->spec_depth);
+        { const int m0 = std::min({ n - start, depth, t->max_batch });
+          for (int i = 0; i < m0; ++i) { keys[i] = t->key_slot; curs[i] = slot[start + i]; }
+          segs.push_back({ -1, start, m0, 0 }); total = m0; }
+        if (t->last_gap > 0) {
+            int kidx = start + t->last_gap - 1;
+            for (int c = 0; c < t->spec_chain && kidx < n - 1 && kidx < start + segs[0].count; ++c, kidx += t->last_gap) {
+                const int first = kidx + 1, ms = std::min({ n - first, depth, t->max_batch - total });
+                if (ms <= 0) break;
+                for (int i = 0; i < ms; ++i) { keys[total + i] = slot[kidx]; curs[total + i] = slot[first + i]; }
+                segs.push_back({ kidx, first, ms, total }); total += ms;
+                if (kidx + t->last_gap >= first + ms) break;      // the next guess would lie beyond what this segment registers
+            }
+        }
+        if ((rc = nik_pose_batch(t->ctx, total, keys.data(), curs.data(), 1, res.data()))) return bail(rc);
+        t->gpu_calls += 1;
+        size_t sg = 0;
+        for (;;) {
+            const Seg& S = segs[sg];
+            int i = 0; bool inserted = false;
+            const int prev_key_frame = t->key_frame_id;
+            while (i < S.count && !inserted) { inserted = apply_result(t, res[S.res_off + i], slot[S.first + i], out[S.first + i]); ++i; }
+            start = S.first + i;
+            if (inserted) {
+                t->last_gap = std::max(1, t->key_frame_id - prev_key_frame);
+                t->spec_depth = std::min(t->max_batch, std::max(4, 2 * t->last_gap));
+            } else {
+                t->spec_depth = std::min(t->max_batch, 2 * std::max(1, t->spec_depth));
+            }
+            // the next segment is usable iff its guessed key is the frame that has just been inserted
+            if (inserted && sg + 1 < segs.size() && segs[sg + 1].key_idx == start - 1) { ++sg; t->spec_hits += 1; continue; }
+            if (sg + 1 < segs.size()) t->spec_misses += 1;
+            // the chain grows while the guesses hold and collapses when one fails
+            if (inserted && (segs.size() == 1 || sg + 1 == segs.size())) t->spec_chain = std::min(6, t->spec_chain + 1);
+            else if (sg + 1 < segs.size()) t->spec_chain = 0;
+            break;
+        }
     }
     // recycle the slots of frames that did not become keyframes
     for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]);

@@ -142,3 +142,41 @@ def test_tracker_with_map_finds_loops():
     with pytest.raises(N.NikError):
         trk.attach_map(kmap, True)              # too late: the tracker has started
     trk.close(); kmap.close(); flow.close()
+
+
+@pytest.mark.gpu
+def test_keyframe_chain_speculation_changes_nothing():
+    """A regular trajectory (a keyframe every few frames): push_dev registers the frames behind its GUESSED next keyframes in
+    the batch that serves the current one.  The outputs must be exactly those of pushing the frames one at a time (no
+    speculation possible there), most guesses must hold, and the batched calls must be far fewer than the keyframes."""
+    import torch
+    N = nik()
+    geom = SMALL
+    H, W = geom["H"], geom["W"]
+    n, window = 96, 32
+    cv = synth.canvas(31, H, W)
+    frames = np.stack([synth.window(cv, H, W, (i % 24) - 12, 2 * (i % 24) - 24, 0.0) for i in range(n)])     # steady ramps of 24 frames
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    tc = N.tracker_config(fx=600.0 * W / 640, fy=600.0 * W / 640, cx=W / 2 - 3.5, cy=H / 2 + 2.25, height=0.1,
+                          max_distance=0.1, max_angle=0.02, lower_response_thr=8.0, upper_response_thr=9.0)
+    d = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+    flow = N.CorrelationFlow(cfg, H, W, max_batch=window, max_frames=n + window + 2)
+    trk = N.Tracker(flow, tc)
+    got = []
+    for b in range(0, n, window):
+        got += trk.push_dev(d[b:b + window].data_ptr(), min(window, n - b))
+    held, failed, calls = trk.speculation()
+    flow1 = N.CorrelationFlow(cfg, H, W, max_batch=1, max_frames=n + 3)
+    trk1 = N.Tracker(flow1, tc)
+    one = []
+    for i in range(n):
+        one += trk1.push_dev(d[i:i + 1].data_ptr(), 1)
+    for a, b in zip(got, one):
+        for k in ("frame_id", "inserted", "good_tracking", "key_frame_id", "response", "cf_pose", "robot_pose", "distance"):
+            assert a[k] == b[k], (a["frame_id"], k, a[k], b[k])
+    n_key = sum(o["inserted"] for o in got)
+    assert 8 <= n_key < n - 8, n_key
+    assert held >= 4 and held > failed, (held, failed)
+    assert calls <= n_key - held + n // window, (calls, n_key, held)         # every guess that held saved one batched call (a push may end mid-segment)
+    assert trk1.speculation()[0] == 0
+    trk.close(); trk1.close(); flow.close(); flow1.close()
