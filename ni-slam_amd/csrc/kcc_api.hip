@@ -317,12 +317,17 @@ int retire(nik_ctx* c, Call& call) {
     return NIK_OK;
 }
 
+// Lanes beyond active_lanes never hold work (nik_set_streams drains before it changes the count): the stream plumbing below
+// touches the active ones only -- every event call costs host time, and a chained pyramid issues dozens per batch
+// (three allocated lanes instead of one cost the pyramid workload 30 %).
 int drain_all(nik_ctx* c) {
-    for (Lane& L : c->lanes)
+    for (int li = 0; li < c->active_lanes; ++li) {
+        Lane& L = c->lanes[li];
         for (int k = 0; k < L.ring_n; ++k) {        // oldest call first
             int rc = retire(c, L.ring[(L.next + k) % L.ring_n]);
             if (rc) return rc;
         }
+    }
     return NIK_OK;
 }
 
@@ -634,6 +639,13 @@ void lane_free(Lane& L) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
 }
 
+// streams and work buffers of lanes [0, n): created on first use
+int ensure_lanes(nik_ctx* c, int n) {
+    for (int li = 0; li < n && li < (int)c->lanes.size(); ++li)
+        if (!c->lanes[li].stream) { int rc = lane_alloc(c, c->lanes[li], (int)c->lanes.size()); if (rc) return rc; }
+    return NIK_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -694,9 +706,14 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
     int nl = 3;                                   // measured: 3 streams beat 2 by 1-3 % at 256 pairs per call (tools/sweep_chunk.sh)
     if (const char* e = getenv("NIK_STREAMS")) nl = atoi(e);
-    nl = std::max(1, std::min(4, nl));
+    // (a call of n items uses n / 32 streams at most -- lanes_for(): a context whose batches are small never needs the others;
+    // unused streams are not free: the pyramid workload lost 30 % to two idle lanes per level)
+    nl = std::max(1, std::min({ 4, nl, std::max(1, max_batch / 32) }));
+    // lane 0 now, the others when a call first needs them (ensure_lanes): a stream that exists takes a hardware queue slot
+    // from the ones that work, and a context that is switched to one stream right after creation (the pyramid's levels)
+    // should never pay for the others
     c->lanes.resize(nl); c->active_lanes = nl;
-    for (Lane& L : c->lanes) if ((rc = lane_alloc(c, L, nl))) return bail(rc);
+    if ((rc = lane_alloc(c, c->lanes[0], nl))) return bail(rc);
     TRY_C(hipMalloc(&c->d_u8, (size_t)H * W));
     TRY_C(hipMalloc(&c->d_scratch, sizeof(float) * std::max(c->img.real_elems, 2 * c->spec_max) * 2));
     if ((rc = build_polar_table(c)) || (rc = build_rot_table(c))) return bail(rc);
@@ -812,7 +829,7 @@ int nik_set_undistort(nik_ctx* c, const int16_t* map1, const uint16_t* map2) {
     if (!c || ((map1 == nullptr) != (map2 == nullptr))) return fail(c, NIK_ERR_INVALID_ARG, "both maps or neither");
     int rc = drain_all(c);
     if (rc) return rc;
-    for (Lane& L : c->lanes) HIP_TRY(c, hipStreamSynchronize(L.stream));
+    for (Lane& L : c->lanes) if (L.stream) HIP_TRY(c, hipStreamSynchronize(L.stream));
     (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2); c->ud_map1 = nullptr; c->ud_map2 = nullptr;
     if (!map1) return NIK_OK;
     const size_t n = c->img.real_elems;
@@ -845,7 +862,7 @@ int nik_synchronize(nik_ctx* c) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc = drain_all(c);
     if (rc) return rc;
-    for (Lane& L : c->lanes) HIP_TRY(c, hipStreamSynchronize(L.stream));
+    for (int li = 0; li < c->active_lanes; ++li) if (c->lanes[li].stream) HIP_TRY(c, hipStreamSynchronize(c->lanes[li].stream));
     return NIK_OK;
 }
 
@@ -856,6 +873,7 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
     int rc;
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, dst[i], false))) return rc;
     const int nl = lanes_for(c, n);
+    if ((rc = ensure_lanes(c, nl))) return rc;
     for (int li = 0; li < nl; ++li) {
         int b, e; chunk_of(n, nl, li, b, e);
         const int m = e - b; if (m <= 0) continue;
@@ -1013,6 +1031,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
+    if ((rc = ensure_lanes(c, nl))) return rc;
     // chunks: one per lane, or -- $NIK_CHUNK / nik_set_chunk -- pieces of at most chunk_pairs pairs dealt to the lanes in turn.
     // Small chunks keep a kernel's output in the 256 MiB Infinity Cache until the next kernel of the lane reads it.
     int nc = nl;
@@ -1186,9 +1205,12 @@ int nik_wait_for(nik_ctx* c, nik_ctx* other) {
     if (!c || !other) return NIK_ERR_INVALID_ARG;
     if (other->device != c->device) return fail(c, NIK_ERR_INVALID_ARG, "contexts on different devices");
     if (!other->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&other->fence_ev, hipEventDisableTiming));
-    for (Lane& O : other->lanes) {
-        HIP_TRY(c, hipEventRecord(other->fence_ev, O.stream));
-        for (Lane& L : c->lanes) HIP_TRY(c, hipStreamWaitEvent(L.stream, other->fence_ev, 0));
+    int rc = ensure_lanes(c, c->active_lanes);
+    if (rc) return rc;
+    for (int lo = 0; lo < other->active_lanes; ++lo) {
+        if (!other->lanes[lo].stream) continue;
+        HIP_TRY(c, hipEventRecord(other->fence_ev, other->lanes[lo].stream));
+        for (int li = 0; li < c->active_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, other->fence_ev, 0));
     }
     return NIK_OK;
 }
@@ -1205,8 +1227,9 @@ int nik_set_call_depth(nik_ctx* c, int depth) {
 int nik_stream_wait_ctx(nik_ctx* c, void* stream) {
     if (!c) return NIK_ERR_INVALID_ARG;
     if (!c->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fence_ev, hipEventDisableTiming));
-    for (Lane& L : c->lanes) {
-        HIP_TRY(c, hipEventRecord(c->fence_ev, L.stream));
+    for (int li = 0; li < c->active_lanes; ++li) {
+        if (!c->lanes[li].stream) continue;                  // (never used: nothing to wait for)
+        HIP_TRY(c, hipEventRecord(c->fence_ev, c->lanes[li].stream));
         HIP_TRY(c, hipStreamWaitEvent((hipStream_t)stream, c->fence_ev, 0));
     }
     return NIK_OK;
@@ -1215,8 +1238,10 @@ int nik_stream_wait_ctx(nik_ctx* c, void* stream) {
 int nik_ctx_wait_stream(nik_ctx* c, void* stream) {
     if (!c) return NIK_ERR_INVALID_ARG;
     if (!c->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fence_ev, hipEventDisableTiming));
+    int rc = ensure_lanes(c, c->active_lanes);
+    if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->fence_ev, (hipStream_t)stream));
-    for (Lane& L : c->lanes) HIP_TRY(c, hipStreamWaitEvent(L.stream, c->fence_ev, 0));
+    for (int li = 0; li < c->active_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->fence_ev, 0));
     return NIK_OK;
 }
 // 2x2 box filter of n frames of c's geometry on a caller-owned stream
@@ -1302,6 +1327,7 @@ int nik_rgb_to_gray_async(nik_ctx* c, int n, const uint8_t* d_rgb, int bgr, uint
     if (!c || !d_rgb || !d_gray || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
     if (n == 0) return NIK_OK;
     if (!c->fence_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->fence_ev, hipEventDisableTiming));
+    { int rce = ensure_lanes(c, c->active_lanes); if (rce) return rce; }
     // the conversion overwrites d_gray: it must come after whatever the other streams still read from it
     for (int li = 1; li < c->active_lanes; ++li) {
         HIP_TRY(c, hipEventRecord(c->fence_ev, c->lanes[li].stream));
@@ -1351,6 +1377,7 @@ static int rotation_call(nik_ctx* c, int n, const nik_frame* keys, const nik_fra
     struct Part { Lane* L; Call* call; int b, m; };
     std::vector<Part> parts;
     const int nl = lanes_for(c, n);
+    if ((rc = ensure_lanes(c, nl))) return rc;
     for (int li = 0; li < nl; ++li) {
         int b, e; chunk_of(n, nl, li, b, e);
         const int m = e - b; if (m <= 0) continue;
