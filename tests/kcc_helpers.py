@@ -35,7 +35,7 @@ def ang_diff(a, b):
 
 # relative gap between the rotation arg-max and its 180-degree mirror below which the two peaks are a
 # rounding-noise tie (the polar source is point-symmetric; see DESIGN.md "The 180-degree rotation tie").
-# MEASURED, not guessed (tests/test_gpu_wide.py::test_response_noise_bounds_the_tie_tolerance, profiles/r02_response_noise.json):
+# MEASURED, not guessed (tests/test_gpu_wide.py::test_response_noise_bounds_the_tie_tolerance, profiles/r03_response_noise.json):
 # from identical float32 spectra the rotation response of the CPU float32 oracle deviates from the float64 evaluation by
 # up to 6.0e-4 of the peak and the HIP path by up to 5.8e-4 (EstimateTrans divides by Kzz + lambda, whose small bins carry
 # percent-level float32 error); two peaks closer than the sum of those deviations (1.2e-3) can legitimately swap.  The

@@ -97,7 +97,7 @@ def test_response_noise_bounds_the_tie_tolerance():
                          rot_argmax_hip_eq_oracle=bool(int(np.argmax(g)) == int(np.argmax(g_o)))))
         assert int(np.argmax(gt)) == int(np.argmax(gt_o)) == int(np.argmax(gt64)), "translation arg-max (isolated peak)"
     w = {k: max(r[k] for r in rows) for k in rows[0] if k.endswith(("f64", "oracle")) and not k.startswith("rot_argmax")}
-    _out("r02_response_noise.json", dict(note="max|g_a - g_b| / peak of the EstimateTrans response surfaces at 640x480 from identical float32 "
+    _out("r03_response_noise.json", dict(note="max|g_a - g_b| / peak of the EstimateTrans response surfaces at 640x480 from identical float32 "
                                               "spectra: oracle (CPU float32), HIP (nik_dbg_response), float64 evaluation",
                                          ROT_TIE_REL=kcc_helpers.ROT_TIE_REL, worst=w, pairs=rows))
     print(w)
@@ -147,7 +147,7 @@ def test_unique_pairs_parity(small_rot, max_theta):
             assert res[i]["trans_row"][cg] == dbgs[p]["trans_row"][co] and res[i]["trans_col"][cg] == dbgs[p]["trans_col"][co]
     g = np.array([x for x in gaps if x is not None])
     hist = np.histogram(g, bins=[0, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3])[0].tolist() if g.size else []
-    _out("r02_unique_pairs_%s.json" % ("small" if small_rot else "large"),
+    _out("r03_unique_pairs_%s.json" % ("small" if small_rot else "large"),
          dict(pairs=n, mode="not_large_rotation=%s" % small_rot, max_theta=max_theta, rotation_argmax=kinds, ROT_TIE_REL=kcc_helpers.ROT_TIE_REL,
               accepted_mirror_tie_gap_hist=dict(bins=[0, 1e-6, 3e-6, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3], counts=hist),
               max_accepted_gap=float(g.max()) if g.size else 0.0))

@@ -10,7 +10,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 B=$([ "$WL" = hd ] && echo 128 || echo 256)
 python $R/tools/rocprof_summary.py $TAG $OUT $B -- python $R/bench.py --workload $WL --steps 6 --warmup 2 --cpu-sample 0 --no-profile --no-cached --no-live-prof
-for f in kernel_stats.csv kernel_times.json pmc_hbm_summary.csv pmc_traffic.json; do cp $OUT/${TAG}_$f $R/profiles/ 2>/dev/null; done
+# (gpurun merges gpurun_out/ back, not profiles/: copy gpurun_out/${TAG}_* into profiles/ afterwards)
 cd $R && python bench.py --workload $WL --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python -c "
 import json; d=json.load(open('$OUT/${TAG}_bench.json')); print(d['value'], d['roofline'], d['cpu_baseline'], d.get('kzz_cached_mode'))"
