@@ -86,7 +86,7 @@ struct Member {                 // one GPU of this process
     nik_ctx* ctx = nullptr;
     int device = 0, rank = 0;
     ncclComm_t comm = nullptr;
-    double* d_buf = nullptr;    // [4] all-reduced statistics | [8] my best record | [8 * world] gathered records
+    double* d_buf = nullptr;    // [4] all-reduced statistics | [8] my best record | [8 * world] gathered records | [1] pose-graph cost
     double* h_buf = nullptr;    // pinned mirror
     hipStream_t stream = nullptr;   // the context's statistics stream once statistics were requested, else a private one
     hipStream_t own_stream = nullptr;
@@ -125,8 +125,8 @@ int gfail(nik_group* g, int code, const std::string& msg) {
 
 int member_init(nik_group* g, Member& mb) {
     G_HIP(g, hipSetDevice(mb.device));
-    G_HIP(g, hipMalloc(&mb.d_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world)));
-    G_HIP(g, hipHostMalloc(&mb.h_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world)));
+    G_HIP(g, hipMalloc(&mb.d_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world + 1)));
+    G_HIP(g, hipHostMalloc(&mb.h_buf, sizeof(double) * (size_t)(4 + 8 + 8 * g->world + 1)));
     G_HIP(g, hipStreamCreateWithFlags(&mb.own_stream, hipStreamNonBlocking));
     G_HIP(g, hipEventCreateWithFlags(&mb.done, hipEventDisableTiming));
     mb.stream = mb.own_stream;
@@ -367,6 +367,7 @@ int nik_group_gather_best(nik_group* g, const int* global_index, const nik_pose_
 int nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const double* poses, double* cost) {
     if (!g || !shards || !cost) return NIK_ERR_INVALID_ARG;
     const bool multi = g->use_rccl;
+    const size_t PG = (size_t)(12 + 8 * g->world);           // its own slot: a residual all-reduce may be in flight in [0, 4)
     std::vector<double*> src(g->m.size(), nullptr);
     std::vector<hipStream_t> st(g->m.size(), nullptr);
     for (size_t i = 0; i < g->m.size(); ++i) {
@@ -384,10 +385,10 @@ int nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const d
         hipError_t he = hipSetDevice(mb.device);
         if (he != hipSuccess) { first_err = std::string("hipSetDevice: ") + hipGetErrorString(he); break; }
         if (multi) {
-            const ncclResult_t nr = rccl().AllReduce(src[i], mb.d_buf, 1, ncclDouble, ncclSum, mb.comm, st[i]);
+            const ncclResult_t nr = rccl().AllReduce(src[i], mb.d_buf + PG, 1, ncclDouble, ncclSum, mb.comm, st[i]);
             if (nr != ncclSuccess) first_err = std::string("ncclAllReduce: ") + rccl().GetErrorString(nr);
         } else {
-            he = hipMemcpyAsync(mb.d_buf, src[i], sizeof(double), hipMemcpyDeviceToDevice, st[i]);
+            he = hipMemcpyAsync(mb.d_buf + PG, src[i], sizeof(double), hipMemcpyDeviceToDevice, st[i]);
             if (he != hipSuccess) first_err = std::string("hipMemcpyAsync: ") + hipGetErrorString(he);
         }
     }
@@ -395,10 +396,10 @@ int nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const d
     if (!first_err.empty()) return gfail(g, NIK_ERR_HIP, first_err);
     Member& m0 = g->m[0];
     G_HIP(g, hipSetDevice(m0.device));
-    G_HIP(g, hipMemcpyAsync(m0.h_buf, m0.d_buf, sizeof(double), hipMemcpyDeviceToHost, st[0]));
+    G_HIP(g, hipMemcpyAsync(m0.h_buf + PG, m0.d_buf + PG, sizeof(double), hipMemcpyDeviceToHost, st[0]));
     for (size_t i = 0; i < g->m.size(); ++i) { G_HIP(g, hipSetDevice(g->m[i].device)); G_HIP(g, hipStreamSynchronize(st[i])); }
     // (a local group without RCCL -- one member -- has nothing to add up; with several local members RCCL summed them)
-    *cost = m0.h_buf[0];
+    *cost = m0.h_buf[PG];
     return NIK_OK;
 }
 
