@@ -113,8 +113,9 @@ int main(int argc, char** argv) {
         // #1-#3  cv::warpPolar exactly as CorrelationFlow::polar calls it (correlation_flow.cc:228-236)
         CFConfig cfg = make_cfg(h, w, pd, pc); double dh = h, dw = w;
         CorrelationFlow cf(cfg, dh, dw);
-        // (CorrelationFlow::polar itself is an `inline` member defined in the reference's .cc: no out-of-line symbol to link
-        // against, so its four statements are repeated here with the same arguments)
+        // (CorrelationFlow::polar is an `inline` member defined inside the reference's .cc -- there is no out-of-line symbol to link
+        // against -- so RECALLED.md #1 is pinned by calling cv::warpPolar here with the arguments documented there: dsize =
+        // (rotation_channel, rotation_divisor), centre (cols/2, rows/2) as floats, maxRadius = min(rows/2, cols/2), linear mode)
         {
             cv::Mat polar_img, img = ConvertArrayToMat(x);
             cv::Point2f center((float)img.cols / 2, (float)img.rows / 2);
