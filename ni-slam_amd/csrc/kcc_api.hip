@@ -34,7 +34,7 @@ struct Family {                 // one plane geometry with its tables
     Tables t{};
     size_t real_elems = 0;      // rows*cols
     size_t spec_elems = 0;      // hr*cols
-    float2* d_tw[7] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    float2* d_tw[9] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 };
 
 // index arrays of one call (each cap_items ints)
@@ -197,7 +197,9 @@ int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     if ((rc = upload_table(c, plan_table(ph, false), &f.d_tw[0])) || (rc = upload_table(c, plan_table(ph, true), &f.d_tw[1])) ||
         (rc = upload_table(c, twiddles(rows, h), &f.d_tw[2])) ||
         (rc = upload_table(c, plan_table(pc, false), &f.d_tw[3])) || (rc = upload_table(c, plan_table(pc, true), &f.d_tw[4])) ||
-        (rc = upload_table(c, plan_table(plan_desc_inv(h), false), &f.d_tw[5])) || (rc = upload_table(c, plan_table(plan_desc_inv(h), true), &f.d_tw[6]))) return rc;
+        (rc = upload_table(c, plan_table(plan_desc_inv(h), false), &f.d_tw[5])) || (rc = upload_table(c, plan_table(plan_desc_inv(h), true), &f.d_tw[6])) ||
+        (rc = upload_table(c, plan_table(plan_desc_alt(cols), false), &f.d_tw[7])) || (rc = upload_table(c, plan_table(plan_desc_alt(cols), true), &f.d_tw[8]))) return rc;
+    f.t.colsA_f = f.d_tw[7]; f.t.colsA_i = f.d_tw[8];
     f.t.halfI_f = f.d_tw[5]; f.t.halfI_i = f.d_tw[6];
     f.t.half_f = f.d_tw[0]; f.t.half_i = f.d_tw[1]; f.t.tw_full = f.d_tw[2]; f.t.cols_f = f.d_tw[3]; f.t.cols_i = f.d_tw[4];
     return NIK_OK;

@@ -182,6 +182,16 @@ template <> struct PlanFor<448> : Plan<448, 7, 8, 8> {};
 template <> struct PlanFor<600> : Plan<600, 24, 25> {};
 template <> struct PlanFor<1600> : Plan<1600, 10, 10, 16> {};
 
+// Plan of the SINGLE-plane B kernels (fwd_abs_inv, the Kzz-cached *_x / solve_cached / zz_inv modes, plain fwd / inv): with one
+// plane per thread a two-pass plan's large radices fit the register budget, and 640 = 20 x 32 (32 threads per line: two passes,
+// three barriers fewer per transform) beats 8 x 8 x 10 there (fwd_abs_inv 0.187 -> 0.169 ms); the two-plane kernels lose with it
+// (registers) and keep PlanFor.  Default: the same plan.
+template <int N> struct PlanAlt : PlanFor<N> {};
+#ifndef KCC_PA640
+#define KCC_PA640 20, 32
+#endif
+template <> struct PlanAlt<640> : Plan<640, KCC_PA640> {};
+
 // Plan used by the spectrum-in (inverse) A-type kernels; may differ from PlanFor (their tile width, hence their
 // thread budget, differs).  Default: the same plan.
 template <int N> struct PlanInv : PlanFor<N> {};

@@ -51,12 +51,15 @@ struct Tables {
     const float2* tw_full;   // W_{2h}^k, k < h: r2c / c2r split twiddles
     const float2* cols_f;    // plan of length cols, forward
     const float2* cols_i;    // plan of length cols, inverse
+    const float2* colsA_f;   // plan of the single-plane B kernels (PlanAlt), forward / inverse
+    const float2* colsA_i;
 };
 
 // radices of the instantiated plan for length n (np = 0 if n is not instantiated)
 struct PlanDesc { int n, np, r[3], t; };      // t: threads per line
 PlanDesc plan_desc(int n);
-PlanDesc plan_desc_inv(int n);   // plan of the spectrum-in A-type kernels for half length n
+PlanDesc plan_desc_inv(int n);
+PlanDesc plan_desc_alt(int n);   // plan of the single-plane B kernels for line length n   // plan of the spectrum-in A-type kernels for half length n
 
 // ---- u8 frame-store image -> f32 column-major plane of the same slot (ConvertMatToNormalizedArray on demand) ----
 // f32 planes have column pitch PH >= H + 4 (rows H..H+3 repeat rows 0..3: vertical wrap taps are contiguous)

@@ -42,6 +42,13 @@ PlanDesc plan_desc_inv(int n_) {
 #undef X
     return d;
 }
+PlanDesc plan_desc_alt(int n_) {
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
+#define X(n) if (n_ == n) { using P = PlanAlt<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
+    KCC_LINE_LIST(X)
+#undef X
+    return d;
+}
 PlanDesc plan_desc(int n_) {
     PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
 #define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
@@ -1283,6 +1290,7 @@ enum { B_FWD = 0, B_FWD_ABS_INV = 1, B_MUL_INV = 2, B_FWD_MUL_INV = 3, B_SOLVE_I
 struct BArgs {
     int cols, hr, ablate, rev;
     CCP tw_f, tw_i;
+    CCP twA_f, twA_i;                                             // tables of PlanAlt (single-plane modes)
     CCP src; size_t src_stride; const int* src_idx;     // primary input
     CCP zsrc; size_t z_stride; const int* z_idx;        // Z (key) spectra
     size_t in_plane_stride;                                       // SOLVE: plane 1 offset inside src item
@@ -1316,8 +1324,8 @@ struct BArgs {
 #define KCC_BLK_BIG2 3
 #endif
 template <int N, int MODE> struct BCfg {
-    using P = PlanFor<N>;
-    static constexpr int T = P::T;
+    using P0 = PlanFor<N>;
+    static constexpr int T0 = P0::T;
     // exchange buffers per line: two for the modes that transform two planes at once, else one
     // SEQ: the two planes of the mode go through ONE exchange buffer one after the other -- half the LDS, twice the
     // waves per CU, one more barrier per chain.  Pays for the ridge solve of the mid-size lines (measured at 480:
@@ -1328,8 +1336,12 @@ template <int N, int MODE> struct BCfg {
 #ifndef KCC_B_SEQ_TMAX
 #define KCC_B_SEQ_TMAX 64
 #endif
-    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T < KCC_B_SEQ_TMAX;
+    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T0 < KCC_B_SEQ_TMAX;
     static constexpr int NV = (!SEQ && (MODE == 2 || MODE == 3 || MODE == 4)) ? 2 : 1;
+    // single-plane modes (not the single-buffer solve, which still holds two planes in registers) use PlanAlt
+    static constexpr bool ALT = !(MODE == 2 || MODE == 3 || MODE == 4);
+    using P = typename std::conditional<ALT, PlanAlt<N>, PlanFor<N>>::type;
+    static constexpr int T = P::T;
     static constexpr int LK = (T >= 128) ? (NV == 2 ? KCC_BLK_HUGE2 : KCC_BLK_HUGE) : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
                                                         : (T >= 20 ? (NV == 2 ? KCC_BLK_MID2 : KCC_BLK_MID) : 16));
     static constexpr int NT = LK * T;
@@ -1376,6 +1388,9 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     const bool nofft = ABL(a, 4);
     const size_t loff = (size_t)k * N + j;
     constexpr int NVM = C::NV;
+    // single-plane modes whose plan puts a line inside one wave (PlanAlt<640>: 32 threads per line): no workgroup barrier
+    // between the passes of a chain, the waves of a workgroup run their lines independently
+    constexpr bool WLB = KCC_WAVE_LOCAL && C::ALT && (64 % C::T == 0);
     cf2* const ex1[1] = { lds + (NVM * lk) * C::EPITCH };
     cf2* const ex2[2] = { lds + (NVM * lk) * C::EPITCH, lds + (NVM * lk + NVM - 1) * C::EPITCH };
 
@@ -1384,20 +1399,20 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         using D = Dir<P, INV>;
         cf2 vin[1][D::RF], vout[1][D::RL];
         load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, D::MF, valid && j < D::MF);
-        if (!nofft) fft_chain<P, INV, 1>(vin, vout, j, ex1, INV ? a.tw_i : a.tw_f);
+        if (!nofft) fft_chain<P, INV, 1, WLB>(vin, vout, j, ex1, INV ? a.tw_i : a.tw_f);
         if (vst && j < D::ML)
             store_strided(vout[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, D::ML);
     } else if (MODE == B_FWD_ABS_INV) {
         // fft_result = FFT(image);  IFFT(fft_result.abs())   (correlation_flow.cc:91-92)
         cf2 vin[1][DF::RF], f[1][DF::RL], o[1][DI::RL];
         load_strided(vin[0], a.src + (size_t)item * a.src_stride + loff, DF::MF, valid && j < DF::MF);
-        if (!nofft) fft_chain<P, false, 1>(vin, f, j, ex1, a.tw_f);
+        if (!nofft) fft_chain<P, false, 1, WLB>(vin, f, j, ex1, a.tw_f);
         if (vst && j < DF::ML)
             store_strided(f[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, DF::ML);
 #pragma unroll
         for (int q = 0; q < DF::RL; ++q) f[0][q] = mk2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
-        __syncthreads();
-        if (!nofft) fft_chain<P, true, 1>(f, o, j, ex1, a.tw_i);
+        line_sync<WLB>();
+        if (!nofft) fft_chain<P, true, 1, WLB>(f, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) {
             cf2* d2 = a.dst2 + (size_t)item * a.dst2_stride + loff;
             if (a.zz_half > 0) {                              // only the columns the even-half inverse row pass reads
@@ -1415,7 +1430,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (MODE == B_FWD_MUL_INV) {
             cf2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
-            if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+            if (!nofft) fft_chain<P, false, 1, WLB>(vin, x, j, ex1, a.tw_f);
             if (a.dst2 && vst && j < DF::ML)                 // X is a result of its own (the frame's spectrum): keep it
                 store_strided(x[0], a.dst2 + (size_t)(a.dst2_slot ? a.dst2_slot[item] : item) * a.dst2_stride + loff, DF::ML);
 #pragma unroll
@@ -1433,9 +1448,9 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             if (C::SEQ) {
                 cf2 (&p0)[1][DI::RF] = reinterpret_cast<cf2 (&)[1][DI::RF]>(pr[0]); cf2 (&p1)[1][DI::RF] = reinterpret_cast<cf2 (&)[1][DI::RF]>(pr[1]);
                 cf2 (&o0)[1][DI::RL] = reinterpret_cast<cf2 (&)[1][DI::RL]>(o[0]);  cf2 (&o1)[1][DI::RL] = reinterpret_cast<cf2 (&)[1][DI::RL]>(o[1]);
-                fft_chain<P, true, 1>(p0, o0, j, ex1, a.tw_i);
+                fft_chain<P, true, 1, WLB>(p0, o0, j, ex1, a.tw_i);
                 __syncthreads();
-                fft_chain<P, true, 1>(p1, o1, j, ex1, a.tw_i);
+                fft_chain<P, true, 1, WLB>(p1, o1, j, ex1, a.tw_i);
             } else {
                 fft_chain<P, true, 2>(pr, o, j, ex2, a.tw_i);
             }
@@ -1457,7 +1472,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         load_strided(zv[0], a.zsrc + (size_t)(a.z_idx ? a.z_idx[item] : item) * a.z_stride + loff, DI::MF, valid && j < DI::MF);
 #pragma unroll
         for (int q = 0; q < DI::RF; ++q) zv[0][q] = mk2(zv[0][q].x * zv[0][q].x + zv[0][q].y * zv[0][q].y, 0.f);
-        if (!nofft) fft_chain<P, true, 1>(zv, o, j, ex1, a.tw_i);
+        if (!nofft) fft_chain<P, true, 1, WLB>(zv, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     } else if (MODE == B_MUL_INV_X || MODE == B_FWD_MUL_INV_X) {
         // Kxz half: X conj Z -> inverse col FFT (plane 1)
@@ -1466,7 +1481,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (MODE == B_FWD_MUL_INV_X) {
             cf2 vin[1][DF::RF], x[1][DF::RL];
             load_strided(vin[0], a.src + (size_t)(a.src_idx ? a.src_idx[item] : item) * a.src_stride + loff, DF::MF, valid && j < DF::MF);
-            if (!nofft) fft_chain<P, false, 1>(vin, x, j, ex1, a.tw_f);
+            if (!nofft) fft_chain<P, false, 1, WLB>(vin, x, j, ex1, a.tw_f);
             if (a.dst2 && vst && j < DF::ML)
                 store_strided(x[0], a.dst2 + (size_t)(a.dst2_slot ? a.dst2_slot[item] : item) * a.dst2_stride + loff, DF::ML);
 #pragma unroll
@@ -1478,7 +1493,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
 #pragma unroll
             for (int q = 0; q < DI::RF; ++q) pr[0][q] = cmulc(xv[q], zv[q]);
         }
-        if (!nofft) fft_chain<P, true, 1>(pr, o, j, ex1, a.tw_i);
+        if (!nofft) fft_chain<P, true, 1, WLB>(pr, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + a.out_plane_stride + loff, DI::ML);
     } else if (MODE == B_SOLVE_CACHED) {
         // as SOLVE_INV, but Kzz (already transformed) and its max come from the key slot's cache
@@ -1488,7 +1503,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         load_strided(kz, a.kzz + (size_t)zslot * a.kzz_stride + loff, DF::ML, valid && j < DF::ML);
         static_assert(C::NT >= 64, "parts_max needs one full wave");
         if (tid < 64) { const float m = parts_max(a.maxbuf + (size_t)(2 * item + 1) * KCC_MAXPARTS, a.n_parts[1], (int)tid); if (tid == 0) s_rmax[1] = m; }
-        if (!nofft) fft_chain<P, false, 1>(vin, kx, j, ex1, a.tw_f);
+        if (!nofft) fft_chain<P, false, 1, WLB>(vin, kx, j, ex1, a.tw_f);
+        if (WLB) __syncthreads();                                     // (wave-local chains hold no workgroup barrier: s_rmax needs one)
         const float rzz = 1.0f / __uint_as_float(a.mzz[zslot]);      // (s_rmax: written before the barriers inside the chain)
         const float rxz = 1.0f / s_rmax[1];
         static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
@@ -1503,7 +1519,7 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
         if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
         __syncthreads();
-        if (!nofft) fft_chain<P, true, 1>(g, o, j, ex1, a.tw_i);
+        if (!nofft) fft_chain<P, true, 1, WLB>(g, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     } else {
         // H = T/(Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l)
@@ -1536,9 +1552,9 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             if (C::SEQ) {
                 cf2 (&v0)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[0]); cf2 (&v1)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[1]);
                 cf2 (&k0)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[0]);  cf2 (&k1)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[1]);
-                fft_chain<P, false, 1>(v0, k0, j, ex1, a.tw_f);
+                fft_chain<P, false, 1, WLB>(v0, k0, j, ex1, a.tw_f);
                 __syncthreads();
-                fft_chain<P, false, 1>(v1, k1, j, ex1, a.tw_f);
+                fft_chain<P, false, 1, WLB>(v1, k1, j, ex1, a.tw_f);
             } else {
                 fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
             }
@@ -1557,12 +1573,14 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         }
         if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
         __syncthreads();
-        if (!nofft) fft_chain<P, true, 1>(g, o, j, ex1, a.tw_i);
+        if (!nofft) fft_chain<P, true, 1, WLB>(g, o, j, ex1, a.tw_i);
         if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
     }
 }
 
-template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a) {
+template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a_in) {
+    BArgs a = a_in;
+    if (BCfg<N, MODE>::ALT) { a.tw_f = a.twA_f; a.tw_i = a.twA_i; }
     constexpr int LK = BCfg<N, MODE>::LK;
     dim3 grid((a.hr + LK - 1) / LK, n_items), block(BCfg<N, MODE>::NT);
     constexpr size_t BYTES = BCfg<N, MODE>::BYTES;
@@ -1592,7 +1610,7 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
 
 static BArgs base_bargs(PlaneGeom g, Tables t) {
     BArgs a{};
-    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.ablate = ablate_flags(); a.rev = g_launch_rev;
+    a.cols = g.cols; a.hr = g.hr; a.tw_f = t.cols_f; a.tw_i = t.cols_i; a.twA_f = t.colsA_f; a.twA_i = t.colsA_i; a.ablate = ablate_flags(); a.rev = g_launch_rev;
     return a;
 }
 
