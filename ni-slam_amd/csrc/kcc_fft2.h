@@ -191,6 +191,8 @@ template <int N> struct PlanAlt : PlanFor<N> {};
 #define KCC_PA640 20, 32
 #endif
 template <> struct PlanAlt<640> : Plan<640, KCC_PA640> {};
+// (measured and not adopted: 1280 = 32 x 40 / 40 x 32 for the single-plane 1280-point kernels -- fwd_abs_inv 0.30 -> 0.34 / 0.37 ms;
+// 480 = 16 x 30 for the Kzz-cached 480-point kernels -- 122.7 k -> 118.3 k candidates/s)
 
 // Plan used by the spectrum-in (inverse) A-type kernels; may differ from PlanFor (their tile width, hence their
 // thread budget, differs).  Default: the same plan.
