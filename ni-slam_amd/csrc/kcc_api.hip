@@ -74,6 +74,7 @@ struct Lane {
     int* d_idx = nullptr;
     Call ring[KCC_RING_MAX]; int ring_n = 2, next = 0;   // ring_n calls in flight before the host blocks on the oldest (nik_set_call_depth)
     Call* cur = nullptr;                // call being enqueued
+    SurfaceResult* mirror = nullptr;    // pinned host mirror for the results of the next enqueue_estimate (consumed by it)
     // hipGraph replay of the pose chain for small batches (nik_set_graphs): one executable per (ring entry, n, mode)
     struct PoseGraph { int slot, n, flags; hipGraphExec_t exec; int uses; };
     std::vector<PoseGraph> graphs;
@@ -519,7 +520,9 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     { Stage st(c, L, kname("kA_inv", f.g.rows / 2, win.row ? "argmax_win" : "argmax", a_tag(c, f)).c_str(), n * Cb(f));
       if (win.row) launch_A_inv_argmax_win(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror);
       else launch_A_inv_argmax(s, n, f.g, f.t, L.gbuf, c->spec_max, L.partials, c->partial_stride); }
-    launch_finalize(s, n, L.partials, c->partial_stride, nb, out, rot_index, n_hyp, c->PD);
+    // (the finalize kernel also writes the results into the call's pinned staging: no device-to-host copy behind it)
+    launch_finalize(s, n, L.partials, c->partial_stride, nb, out, rot_index, n_hyp, c->PD, L.mirror);
+    L.mirror = nullptr;
 }
 
 // ComputePose (correlation_flow.cc:97-143) for n pairs; key/cur slots in the lane's IX_KEY / IX_CUR arrays.
@@ -536,6 +539,7 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
         wtr.row = didx(L, IX_WTR); wtr.col = didx(L, IX_WTC); wtr.radius = win_radius; wtr.mirror = 0;
     }
     // rotation stage: z = key polar spectrum, x = current polar spectrum
+    L.mirror = L.cur->h_rot;
     if (polar_in_tmpA)
         enqueue_estimate(c, L, n, c->pol, true, L.tmpA, c->spec_max, nullptr,
                          c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp,
@@ -554,6 +558,7 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
         launch_A_fwd_rot(s, nt, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_tab,
                          didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
     }
+    L.mirror = L.cur->h_trans;
     if (c->cfg.kernel == 1) {
         // gaussian needs sum|X|^2 of the rotated image's spectrum: materialise X (B forward, in place) first
         launch_B_fwd(s, nt, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
@@ -563,8 +568,6 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
         enqueue_estimate(c, L, nt, c->img, true, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
                          didx(L, IX_TKEY), L.trans_res, nullptr, 1, nullptr, 0, nullptr, wtr);
     }
-    HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * n, hipMemcpyDeviceToHost, s));
-    HIP_TRY(c, hipMemcpyAsync(L.cur->h_trans, L.trans_res, sizeof(SurfaceResult) * nt, hipMemcpyDeviceToHost, s));
     return NIK_OK;
 }
 
@@ -1390,9 +1393,9 @@ static int rotation_call(nik_ctx* c, int n, const nik_frame* keys, const nik_fra
             note_read(c, L, li, keys[i]); note_read(c, L, li, curs[i]);
         }
         if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, 1, false))) return rc;
+        L.mirror = L.cur->h_rot;
         enqueue_estimate(c, L, m, c->pol, false, c->arena_P, c->pol.spec_elems, didx(L, IX_CUR),
                          c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, nullptr, 1);
-        HIP_TRY(c, hipMemcpyAsync(L.cur->h_rot, L.rot_res, sizeof(SurfaceResult) * m, hipMemcpyDeviceToHost, L.stream));
         HIP_TRY(c, hipGetLastError());
         L.cur->has_pose = false;
         if ((rc = end_call(c, L))) return rc;

@@ -190,7 +190,7 @@ void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, 
 // reduce partials -> SurfaceResult per item; rot_index (optional): de-rotation table index of the n_hyp
 // translation items of each pair, variant(h) * PD + arg-max row
 void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials,
-                     SurfaceResult* out, int* rot_index, int n_hyp, int PD);
+                     SurfaceResult* out, int* rot_index, int n_hyp, int PD, SurfaceResult* host_out = nullptr);   // host_out: pinned mirror of out (or null)
 
 
 // residual statistics of a batch call from its raw surface results: stats[4] = [sum PSR_t, sum PSR_r, sum |t|^2, count]

@@ -1743,7 +1743,7 @@ void launch_energy(hipStream_t s, int n_items, PlaneGeom g, const float2* xsrc, 
 // surface also emit the de-rotation table index of every translation item of the pair:
 //   rot_index[item*n_hyp + h] = variant(h) * PD + arg-max row       (variant 0: small-rotation fold, 1/2: orig / +180)
 __global__ __launch_bounds__(64) void k_finalize(const Partial* __restrict__ partials, int partial_stride, int n_partials,
-                                                 SurfaceResult* out, int* rot_index, int n_hyp, int PD) {
+                                                 SurfaceResult* out, int* rot_index, int n_hyp, int PD, SurfaceResult* host_out) {
     const int item = blockIdx.x, lane = threadIdx.x;
     const Partial* p = partials + (size_t)item * partial_stride;
     // one wave: lane i folds partials i, i+64, ... in index order, then a fixed butterfly -> deterministic
@@ -1760,13 +1760,14 @@ __global__ __launch_bounds__(64) void k_finalize(const Partial* __restrict__ par
     if (lane == 0) {
         SurfaceResult r; r.sum = s1; r.sumsq = s2; r.peak = peak; r.idx = idx;
         out[item] = r;
+        if (host_out) host_out[item] = r;                     // pinned host mirror: the result needs no copy of its own
         if (rot_index)
             for (int h = 0; h < n_hyp; ++h) rot_index[item * n_hyp + h] = (n_hyp == 1 ? 0 : 1 + h) * PD + (idx % PD);
     }
 }
 void launch_finalize(hipStream_t s, int n_items, const Partial* partials, int partial_stride, int n_partials, SurfaceResult* out,
-                     int* rot_index, int n_hyp, int PD) {
-    hipLaunchKernelGGL(k_finalize, dim3(n_items), dim3(64), 0, s, partials, partial_stride, n_partials, out, rot_index, n_hyp, PD);
+                     int* rot_index, int n_hyp, int PD, SurfaceResult* host_out) {
+    hipLaunchKernelGGL(k_finalize, dim3(n_items), dim3(64), 0, s, partials, partial_stride, n_partials, out, rot_index, n_hyp, PD, host_out);
 }
 
 // Residual statistics of one batch call, on the device (north star: "RCCL all-reduce only for the final pose-graph residual
