@@ -70,6 +70,7 @@ struct Lane {
     uint8_t* u8tmp = nullptr;           // [cap_pairs][H*W] undistorted frames (allocated by nik_set_undistort)
     Partial* partials = nullptr;
     unsigned* maxbuf = nullptr; float* energy = nullptr;
+    std::vector<int> idx_shadow; int idx_shadow_n[5] = { 0, 0, 0, 0, 0 }; bool idx_force = false;   // host mirror of d_idx[0, IX_ROTIDX) and the valid prefix of each array
     SurfaceResult* rot_res = nullptr; SurfaceResult* trans_res = nullptr;
     int* d_idx = nullptr;
     Call ring[KCC_RING_MAX]; int ring_n = 2, next = 0;   // ring_n calls in flight before the host blocks on the oldest (nik_set_call_depth)
@@ -252,8 +253,20 @@ int build_rot_table(nik_ctx* c) {
 inline int* didx(Lane& L, int which) { return L.d_idx + (size_t)which * L.cap_items; }
 inline int* hidx(Lane& L, int which) { return L.cur->h_idx + (size_t)which * L.cap_items; }
 
+// The device copy of an index array is left alone when it already holds these values (a tracker or a pyramid level that
+// works on the same slots call after call): one stream operation fewer per call, which is what small batches are bound by.
+// L.idx_shadow mirrors what the host has uploaded into d_idx[0, IX_ROTIDX) (the arrays behind are written by kernels).
+inline bool idx_unchanged(Lane& L, int which, int n) {
+    return n <= L.idx_shadow_n[which] && memcmp(L.idx_shadow.data() + (size_t)which * L.cap_items, hidx(L, which), sizeof(int) * n) == 0;
+}
+inline void idx_remember(Lane& L, int which, int n) {
+    memcpy(L.idx_shadow.data() + (size_t)which * L.cap_items, hidx(L, which), sizeof(int) * n);
+    L.idx_shadow_n[which] = n;
+}
 int upload_idx(nik_ctx* c, Lane& L, int which, int n) {
+    if (which < IX_ROTIDX && idx_unchanged(L, which, n)) return NIK_OK;
     HIP_TRY(c, hipMemcpyAsync(didx(L, which), hidx(L, which), sizeof(int) * n, hipMemcpyHostToDevice, L.stream));
+    if (which < IX_ROTIDX) idx_remember(L, which, n);
     return NIK_OK;
 }
 
@@ -582,7 +595,13 @@ int stage_pose_indices(nik_ctx* c, Lane& L, int n, const nik_frame* keys, const 
         hidx(L, IX_TIMG)[t] = curs[p];
         hidx(L, IX_TKEY)[t] = keys[p];
     }
+    const int used[IX_ROTIDX] = { n, n, with_dst ? n : 0, nt, nt };
+    bool same = true;
+    for (int w = 0; w < IX_ROTIDX; ++w) same = same && idx_unchanged(L, w, used[w]);
+    if (same && !L.idx_force) return NIK_OK;
     HIP_TRY(c, hipMemcpyAsync(L.d_idx, L.cur->h_idx, sizeof(int) * (size_t)L.cap_items * IX_ROTIDX, hipMemcpyHostToDevice, L.stream));
+    // (the copy carries whole arrays: whatever lies behind the used prefixes is no longer what the shadow says)
+    for (int w = 0; w < IX_ROTIDX; ++w) { L.idx_shadow_n[w] = 0; idx_remember(L, w, used[w]); }
     return NIK_OK;
 }
 
@@ -620,6 +639,7 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
     HIP_TRY(c, hipMalloc(&L.rot_res, sizeof(SurfaceResult) * c->max_batch));
     HIP_TRY(c, hipMalloc(&L.trans_res, sizeof(SurfaceResult) * c->max_items));
     HIP_TRY(c, hipMalloc(&L.d_idx, sizeof(int) * c->max_items * IX_COUNT));
+    L.idx_shadow.assign((size_t)c->max_items * IX_ROTIDX, -1);
     for (Call& call : L.ring) {
         HIP_TRY(c, hipHostMalloc(&call.h_idx, sizeof(int) * c->max_items * IX_COUNT));
         HIP_TRY(c, hipHostMalloc(&call.h_rot, sizeof(SurfaceResult) * c->max_batch));
@@ -1084,7 +1104,9 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
             if (!pg->exec) {
                 hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
                 HIP_TRY(c, hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+                L.idx_force = true;                          // the graph must contain the index upload whatever d_idx holds now
                 rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, false);
+                L.idx_force = false;
                 if (!rc) rc = enqueue_pose(c, L, m, not_large_rotation, true, false, -1);
                 if (!rc && c->want_stats)
                     launch_residual_stats(L.stream, L.rot_res, L.trans_res, m, n_hyp, c->H, c->W, c->PD, c->PC, c->d_stats + 4 * (size_t)c->stats_parts);
@@ -1101,6 +1123,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
                 c->stats_parts += 1; c->stats_lanes = std::max(c->stats_lanes, li + 1);
             }
             HIP_TRY(c, hipGraphLaunch(pg->exec, L.stream));
+            for (int w = 0; w < IX_ROTIDX; ++w) L.idx_shadow_n[w] = 0;      // (the replayed copy node rewrote d_idx behind the shadow's back)
             pg->uses += 1;
         } else {
             if ((rc = stage_pose_indices(c, L, m, keys + b, curs + b, not_large_rotation, d_gray != nullptr))) return rc;
