@@ -389,6 +389,10 @@ int nik_wait_for(nik_ctx* ctx, nik_ctx* other);
 int nik_downsample_u8_async(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out);
 /* the same on a caller-owned hipStream_t of ctx's device (no ordering against ctx's own streams) */
 int nik_downsample_u8_stream(nik_ctx* ctx, int n, const uint8_t* d_in, uint8_t* d_out, void* stream);
+/* `steps` (1..3) consecutive levels in one launch on `stream`: na frames of d_a followed by nb frames of d_b (d_b may be NULL
+ * with nb = 0) of ctx's geometry; out[d] receives the na + nb frames of level d + 1 back to back -- the same integers as chained
+ * nik_downsample_u8 calls.  H, W and the pointers must be aligned to 2^steps, else NIK_ERR_UNSUPPORTED_SIZE. */
+int nik_downsample_pyr_u8_stream(nik_ctx* ctx, int steps, int na, const uint8_t* d_a, int nb, const uint8_t* d_b, uint8_t* const* out, void* stream);
 /* `stream` waits for everything ctx has enqueued so far / every stream of ctx waits for what `stream` holds so far */
 int nik_stream_wait_ctx(nik_ctx* ctx, void* stream);
 int nik_ctx_wait_stream(nik_ctx* ctx, void* stream);

@@ -1281,6 +1281,22 @@ int nik_downsample_u8_stream(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_
     return NIK_OK;
 }
 
+// `steps` (1..3) pyramid levels below ctx's geometry in ONE launch on `stream`: frames [0, na) of d_a, then nb frames of d_b
+// (may be null with nb = 0); out[d] receives the na + nb frames of level d + 1, back to back.  The same integers as `steps`
+// chained nik_downsample_u8 calls.  Needs H, W divisible by 2^steps and pointers aligned to 2^steps bytes, else
+// NIK_ERR_UNSUPPORTED_SIZE (the caller falls back to the chained form).
+int nik_downsample_pyr_u8_stream(nik_ctx* c, int steps, int na, const uint8_t* d_a, int nb, const uint8_t* d_b, uint8_t* const* out, void* stream) {
+    if (!c || !d_a || !out || steps < 1 || steps > 3 || na < 0 || nb < 0 || (nb > 0 && !d_b)) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    const uintptr_t m = (uintptr_t)(1 << steps) - 1;
+    uintptr_t bits = (uintptr_t)d_a | (uintptr_t)(nb ? d_b : nullptr) | (uintptr_t)c->H | (uintptr_t)c->W;
+    for (int d = 0; d < steps; ++d) { if (!out[d]) return fail(c, NIK_ERR_INVALID_ARG, "null output"); bits |= (uintptr_t)out[d] << (d + 1); }
+    if (bits & m) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "fused downsample needs sizes and pointers aligned to %d", 1 << steps);
+    if (na + nb == 0) return NIK_OK;
+    launch_downsample_pyr((hipStream_t)stream, steps, d_a, d_b, na, na + nb, c->H, c->W, out);
+    HIP_TRY(c, hipGetLastError());
+    return NIK_OK;
+}
+
 // nik_downsample_u8_dev without the drain: enqueued on nik_stream(ctx)
 int nik_downsample_u8_async(nik_ctx* c, int n, const uint8_t* d_in, uint8_t* d_out) {
     if (!c || !d_in || !d_out || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");

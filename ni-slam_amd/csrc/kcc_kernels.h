@@ -77,6 +77,7 @@ void launch_stitch_touched(hipStream_t s, const int* tmp_weight, int n_cells, in
 void launch_stitch_merge(hipStream_t s, int* data, int* weight, const int* tmp_data, const int* tmp_weight, int n, int existing);
 // 2 x 2 box-filtered half-resolution image (pyramid level)
 void launch_downsample_u8(hipStream_t s, int n, const uint8_t* in, uint8_t* out, int H, int W);
+void launch_downsample_pyr(hipStream_t s, int steps, const uint8_t* a, const uint8_t* b, int na, int nf, int H, int W, uint8_t* const* out);
 // 8-bit RGB/BGR (interleaved) -> gray with OpenCV's integer luma weights
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr);
 

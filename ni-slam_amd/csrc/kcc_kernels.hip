@@ -221,6 +221,61 @@ __global__ void k_downsample_u8(const uint8_t* __restrict__ in, uint8_t* __restr
 void launch_downsample_u8(hipStream_t s, int n, const uint8_t* in, uint8_t* out, int H, int W) {
     hipLaunchKernelGGL(k_downsample_u8, dim3(((H / 2) * (W / 2) + 255) / 256, n), dim3(256), 0, s, in, out, H, W);
 }
+// D consecutive pyramid levels in one launch: a thread owns a 2^D x 2^D block of the source, reads it with 8-byte loads and
+// writes its share of every level (each level is the rounded 2 x 2 box filter of the level above it -- the same integers the
+// chained k_downsample_u8 calls produce).  Frames [0, na) come from `a`, frames [na, nf) from `b` (the key and the current
+// frames of a batch arrive in two buffers); level d's frames are stored back to back in out[d - 1].
+template <int D>
+__global__ __launch_bounds__(256) void k_downsample_pyr(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int na, int H, int W,
+                                                        uint8_t* __restrict__ o1, uint8_t* __restrict__ o2, uint8_t* __restrict__ o3) {
+    constexpr int S = 1 << D;
+    const int Wb = W / S, Hb = H / S;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y;
+    if (i >= Hb * Wb) return;
+    const int r = i / Wb, c = i - r * Wb;
+    const uint8_t* src = (f < na ? a + (size_t)f * H * W : b + (size_t)(f - na) * H * W) + (size_t)(r * S) * W + c * S;
+    unsigned v[S][S];
+#pragma unroll
+    for (int y = 0; y < S; ++y) {
+        if (S == 8) {
+            const uint2 w = *reinterpret_cast<const uint2*>(src + (size_t)y * W);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { v[y][x] = (w.x >> (8 * x)) & 255u; v[y][4 + x] = (w.y >> (8 * x)) & 255u; }
+        } else if (S == 4) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(src + (size_t)y * W);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[y][x] = (w >> (8 * x)) & 255u;
+        } else {
+            const unsigned short w = *reinterpret_cast<const unsigned short*>(src + (size_t)y * W);
+            v[y][0] = w & 255u; v[y][1] = w >> 8;
+        }
+    }
+    uint8_t* const outs[3] = { o1, o2, o3 };
+#pragma unroll
+    for (int d = 1; d <= D; ++d) {
+        const int n = S >> d;                                  // this thread's n x n pixels of level d
+#pragma unroll
+        for (int y = 0; y < n; ++y)
+#pragma unroll
+            for (int x = 0; x < n; ++x) v[y][x] = (v[2 * y][2 * x] + v[2 * y][2 * x + 1] + v[2 * y + 1][2 * x] + v[2 * y + 1][2 * x + 1] + 2u) >> 2;
+        const int Wd = W >> d, Hd = H >> d;
+        uint8_t* o = outs[d - 1] + (size_t)f * Hd * Wd + (size_t)(r * n) * Wd + c * n;
+#pragma unroll
+        for (int y = 0; y < n; ++y) {
+            if (n == 4) *reinterpret_cast<unsigned*>(o + (size_t)y * Wd) = v[y][0] | (v[y][1] << 8) | (v[y][2] << 16) | (v[y][3] << 24);
+            else if (n == 2) *reinterpret_cast<unsigned short*>(o + (size_t)y * Wd) = (unsigned short)(v[y][0] | (v[y][1] << 8));
+            else o[(size_t)y * Wd] = (uint8_t)v[y][0];
+        }
+    }
+}
+// steps in [1, 3]; H and W divisible by 2^steps and every pointer aligned to 2^steps bytes (the caller checks)
+void launch_downsample_pyr(hipStream_t s, int steps, const uint8_t* a, const uint8_t* b, int na, int nf, int H, int W, uint8_t* const* out) {
+    const int S = 1 << steps;
+    dim3 grid(((H / S) * (W / S) + 255) / 256, nf), block(256);
+    if (steps == 1) hipLaunchKernelGGL(k_downsample_pyr<1>, grid, block, 0, s, a, b, na, H, W, out[0], nullptr, nullptr);
+    else if (steps == 2) hipLaunchKernelGGL(k_downsample_pyr<2>, grid, block, 0, s, a, b, na, H, W, out[0], out[1], nullptr);
+    else hipLaunchKernelGGL(k_downsample_pyr<3>, grid, block, 0, s, a, b, na, H, W, out[0], out[1], out[2]);
+}
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr) {
     hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
 }

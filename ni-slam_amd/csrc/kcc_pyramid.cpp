@@ -13,6 +13,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
 #include <vector>
 
 struct nik_pyramid {
@@ -81,21 +82,35 @@ int nik_pyramid_track_dev_async(nik_pyramid* p, int n, const uint8_t* d_key, con
     int rc;
     std::vector<const uint8_t*> key(L), cur(L);
     key[0] = d_key; cur[0] = d_cur;
-    // every level's frames first: level l is the 2x2 box filter of level l - 1, produced on the pyramid's own stream
-    // (after level l has finished reading the previous batch's frames), and level l's streams wait for it.  Nothing
-    // returns to the host, and the box filters of batch k+1 do not queue behind the finest level of batch k.
-    for (int l = 1; l < L; ++l) {
-        if ((rc = nik_stream_wait_ctx(p->ctx[l], p->ds)) ||
-            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, key[l - 1], p->d_key[l], p->ds)) ||
-            (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, cur[l - 1], p->d_key[l] + (size_t)n * p->h[l] * p->w[l], p->ds)) ||
-            (rc = nik_ctx_wait_stream(p->ctx[l], p->ds))) return rc;
-        key[l] = p->d_key[l]; cur[l] = p->d_key[l] + (size_t)n * p->h[l] * p->w[l];
+    // every level's frames first: level l is the 2x2 box filter of level l - 1, produced on the pyramid's own stream -- up to three
+    // levels per launch (nik_downsample_pyr_u8_stream), both frame sets at once.  That stream waits, per level, for the level's
+    // PREVIOUS spectra call only (recorded right behind it, see below): the box filters of batch k+1 neither queue behind the
+    // poses of batch k nor return to the host.
+    for (int l = 1; l < L; ++l) { key[l] = p->d_key[l]; cur[l] = p->d_key[l] + (size_t)n * p->h[l] * p->w[l]; }
+    for (int l0 = 0; l0 + 1 < L; ) {
+        const int steps = std::min(3, L - 1 - l0);
+        uint8_t* outs[3] = { nullptr, nullptr, nullptr };
+        for (int d = 0; d < steps; ++d) outs[d] = p->d_key[l0 + 1 + d];
+        // level 0 arrives in two caller buffers; below it both frame sets sit in one buffer (2n frames)
+        rc = l0 == 0 ? nik_downsample_pyr_u8_stream(p->ctx[0], steps, n, key[0], n, cur[0], outs, p->ds)
+                     : nik_downsample_pyr_u8_stream(p->ctx[l0], steps, 2 * n, key[l0], 0, nullptr, outs, p->ds);
+        if (rc == NIK_ERR_UNSUPPORTED_SIZE) {                 // unaligned caller buffers: one level at a time
+            for (int l = l0 + 1; l <= l0 + steps; ++l)
+                if ((rc = nik_downsample_u8_stream(p->ctx[l - 1], n, key[l - 1], p->d_key[l], p->ds)) ||
+                    (rc = nik_downsample_u8_stream(p->ctx[l - 1], n, cur[l - 1], p->d_key[l] + (size_t)n * p->h[l] * p->w[l], p->ds))) return rc;
+        } else if (rc) return rc;
+        l0 += steps;
     }
+    for (int l = 1; l < L; ++l) if ((rc = nik_ctx_wait_stream(p->ctx[l], p->ds))) return rc;
     // slots 0..n-1 hold the key frames, n..2n-1 the current frames; below level 0 both sets sit in one buffer, the current
     // frames directly behind the n key frames (d_key + n frames), so one 2n-frame call transforms them all
     std::vector<nik_frame> ks(n), cs(n), all(2 * (size_t)n);
     for (int i = 0; i < n; ++i) { ks[i] = i; cs[i] = n + i; all[i] = i; all[n + i] = n + i; }
-    for (int l = L - 1; l >= 1; --l) if ((rc = nik_intermedium_batch_dev(p->ctx[l], 2 * n, key[l], all.data()))) return rc;
+    for (int l = L - 1; l >= 1; --l) {
+        if ((rc = nik_intermedium_batch_dev(p->ctx[l], 2 * n, key[l], all.data()))) return rc;
+        // (the next batch's box filter overwrites d_key[l]: it has to wait for this call, and for nothing behind it)
+        if ((rc = nik_stream_wait_ctx(p->ctx[l], p->ds))) return rc;
+    }
     if ((rc = nik_intermedium_batch_dev(p->ctx[0], n, key[0], ks.data())) ||
         (rc = nik_intermedium_batch_dev(p->ctx[0], n, cur[0], cs.data()))) return rc;
     // coarsest level: plain KCC; finer levels: windows predicted on the device from the level above

@@ -29,7 +29,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
-           "nik_downsample_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
+           "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
            "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
@@ -173,6 +173,7 @@ def load():
         L.nik_pyramid_track_dev_async.argtypes = [P, I, P, P, I, P]
         L.nik_pyramid_synchronize.argtypes = [P]
         L.nik_downsample_u8_stream.argtypes = [P, I, P, P, P]
+        L.nik_downsample_pyr_u8_stream.argtypes = [P, I, I, P, I, P, P, P]
         L.nik_stream_wait_ctx.argtypes = [P, P]
         L.nik_ctx_wait_stream.argtypes = [P, P]
         L.nik_set_call_depth.argtypes = [P, I]
@@ -463,6 +464,13 @@ class CorrelationFlow:
 
     def downsample_u8_dev(self, d_in_ptr, n, d_out_ptr):
         self._chk(self._L.nik_downsample_u8_dev(self._ctx, int(n), C.c_void_p(int(d_in_ptr)), C.c_void_p(int(d_out_ptr))))
+
+    def downsample_pyr_u8(self, steps, na, d_a_ptr, nb, d_b_ptr, out_ptrs, stream=None):
+        """`steps` (1..3) pyramid levels in one launch (nik_downsample_pyr_u8_stream); out_ptrs: device pointers of the levels;
+        returns the C return code (NIK_ERR_UNSUPPORTED_SIZE for unaligned sizes / pointers)"""
+        outs = (C.c_void_p * 3)(*([int(x) for x in out_ptrs] + [0] * (3 - len(out_ptrs))))
+        return self._L.nik_downsample_pyr_u8_stream(self._ctx, int(steps), int(na), C.c_void_p(int(d_a_ptr)), int(nb),
+                                                    C.c_void_p(int(d_b_ptr)) if d_b_ptr else None, outs, C.c_void_p(int(stream)) if stream else None)
 
     def match(self, query, cands, raw=False):
         """raw: hand back the ctypes result array as it is (timing loops: converting thousands of results to dicts costs

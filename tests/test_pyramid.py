@@ -126,3 +126,34 @@ def test_pyramid_batches_in_flight_equal_single_batches():
     # distinct batches did give distinct answers (the comparison above is not vacuous)
     assert len({tuple(alone[b][0][0]["pose"]) for b in range(nb)}) > 1
     pyr.close()
+
+
+@pytest.mark.gpu
+def test_fused_downsample_equals_chained_box_filters():
+    """nik_downsample_pyr_u8_stream: up to three levels per launch, two source buffers -- the integers of the chained 2x2 box
+    filters (the oracle's downsample_u8), and a refusal (not a wrong answer) for unaligned pointers"""
+    import torch
+    N = nik()
+    H, W, na, nb = 120, 160, 3, 2
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, (na, H, W), dtype=np.uint8); b = rng.integers(0, 256, (nb, H, W), dtype=np.uint8)
+    cf = N.CorrelationFlow(N.default_config(rotation_divisor=240, rotation_channel=160), H, W, max_batch=4, max_frames=8)
+    dev = torch.device("cuda:0")
+    da, db = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    want = [np.concatenate([a, b])]
+    for _ in range(3):
+        want.append(np.stack([O.downsample_u8(f) for f in want[-1]]))
+    for steps in (1, 2, 3):
+        outs = [torch.zeros((na + nb, H >> d, W >> d), dtype=torch.uint8, device=dev) for d in range(1, steps + 1)]
+        assert cf.downsample_pyr_u8(steps, na, da.data_ptr(), nb, db.data_ptr(), [o.data_ptr() for o in outs]) == 0
+        torch.cuda.synchronize()
+        for d in range(steps):
+            assert np.array_equal(outs[d].cpu().numpy(), want[d + 1]), (steps, d)
+    # one buffer only, and an unaligned source
+    o1 = torch.zeros((na, H // 2, W // 2), dtype=torch.uint8, device=dev)
+    assert cf.downsample_pyr_u8(1, na, da.data_ptr(), 0, 0, [o1.data_ptr()]) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(o1.cpu().numpy(), want[1][:na])
+    big = torch.zeros(na * H * W + 8, dtype=torch.uint8, device=dev)
+    assert cf.downsample_pyr_u8(3, na, big.data_ptr() + 1, 0, 0, [o.data_ptr() for o in outs]) == N.NIK_ERR_UNSUPPORTED_SIZE
+    cf.close()
