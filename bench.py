@@ -336,8 +336,17 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     H, W, PD, PC = 480, 640, 720, 480
     T = args.frames
     cv = synth.canvas(4242, H, W)
-    base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
-    seq = np.stack([base[i % 64] for i in range(T)])
+    if args.seq_motion == "smooth":
+        # constant speed along a zig-zag (3 px and 2 px per frame, --seq-rot-rate degrees per frame, all three turning together
+        # every 64 frames): what a ground robot's down-looking camera sees; keyframes then come at a near-regular spacing
+        # (the 3-degree rule: every 3 / rate frames)
+        tri = lambda i, half: abs(((i + half) % (2 * half)) - half)               # 0 .. half .. 0
+        base = [synth.window(cv, H, W, 3 * tri(i, 64) - 96, 2 * tri(i, 64) - 64, args.seq_rot_rate * tri(i, 64)) for i in range(128)]
+    else:
+        # saw-tooth motion: the rotation jumps back by 4 degrees every 9 frames and the view jumps every 64 -- keyframes at
+        # irregular spacing (the tracker's guesses of the next keyframe mostly fail)
+        base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
+    seq = np.stack([base[i % len(base)] for i in range(T)])
     d_seq = torch.from_numpy(seq).to(dev)
     win = min(args.batch, 64)
     cfg = N.default_config()
@@ -385,7 +394,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     nkey = int(sum(o["inserted"] for o in outs))
     bpf = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
     return _line("frames/s through the tracker (configs[1] as a sequence)", "frames/s", T / best, 1, args, 1e3 * best,
-                 "configs[1] sequence: %d frames, C++ tracker (keyframe rule, PSR gating), speculative windows of %d, Kzz cached per keyframe" % (T, win),
+                 "configs[1] sequence: %d frames (%s camera path), C++ tracker (keyframe rule, PSR gating), speculative windows of %d, Kzz cached per keyframe" % (T, args.seq_motion, win),
                  bpf, dict(frames=T, window=win, keyframes=nkey, good_tracking=int(sum(o["good_tracking"] for o in outs)),
                            keyframe_guesses_held=spec_box[0], keyframe_guesses_failed=spec_box[1], batched_pose_calls=spec_box[2]),
                  parity_spot_check=parity, roofline=None, cpu_baseline=None,
@@ -492,6 +501,8 @@ def main():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic pairs generated (tiled to --batch); 0 = all of them")
     ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
     ap.add_argument("--frames", type=int, default=2048, help="sequence workload: frames")
+    ap.add_argument("--seq-rot-rate", type=float, default=0.25, help="sequence workload, smooth path: degrees per frame")
+    ap.add_argument("--seq-motion", default="sawtooth", choices=["sawtooth", "smooth"], help="sequence workload: synthetic camera path")
     ap.add_argument("--candidates", type=int, default=4096, help="loop4096 workload: resident key frames")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")

@@ -356,8 +356,11 @@ int  nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses /* NULL: unchang
 int  nik_tracker_edges(const nik_tracker* t, nik_pg_constraint* out, int32_t* types, int cap, int* n);
 int  nik_tracker_optimizations(const nik_tracker* t, nik_pg_summary* last /* may be NULL */);
 /* nik_tracker_push_dev registers, in the batch that serves the current keyframe, also the frames behind the frames it GUESSES to
- * become the next keyframes (regular spacing); out = [guesses that held, guesses that failed, batched pose calls so far] */
+ * become the next keyframes (nik_tracker_guess_gap); out = [guesses that held, guesses that failed, batched pose calls so far] */
 int  nik_tracker_speculation(const nik_tracker* t, long out[3]);
+/* what push_dev expects the next keyframe gap to be after the gaps gaps[0..n) (oldest first): the gap that followed the most
+ * recent earlier occurrence of the longest matching suffix (up to sixteen gaps), else the last gap; 0 for an empty history. */
+int  nik_tracker_guess_gap(const int32_t* gaps, int n);
 
 /* ---- measurement ---------------------------------------------------------------------------- */
 

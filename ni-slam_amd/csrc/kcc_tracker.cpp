@@ -51,8 +51,27 @@ struct nik_tracker {
     std::vector<nik_frame> keyframes;
     int spec_depth = 8;                      // frames registered speculatively per batch (adapts to the keyframe spacing)
     int last_gap = 0;                        // frames between the last two keyframes (0: unknown yet)
-    int spec_chain = 0;                      // further key segments registered in the same batch against GUESSED keyframes
+    std::vector<int> gap_hist;               // the recent keyframe gaps, oldest first (what the next gaps are guessed from)
+    double guess_rate = 0.5;                 // running share of keyframe guesses that held
     long spec_hits = 0, spec_misses = 0, gpu_calls = 0;      // diagnostics (nik_tracker_speculation)
+
+    // The gap that followed the most recent earlier occurrence of the current context -- the last sixteen gaps, else the last
+    // fifteen, ... else the last one; without any such occurrence, the last gap again.  Regular spacing and periodic patterns
+    // (6, 3, 6, 3, ... with an irregular beat every few periods) are guessed right; anything else costs a few wasted
+    // registrations.
+    static int guess_next_gap(const std::vector<int>& h) {
+        const int n = (int)h.size();
+        if (n == 0) return 0;
+        for (int order = 16; order >= 1; --order) {
+            if (n <= order) continue;
+            for (int j = n - 2; j >= order - 1; --j) {
+                bool same = true;
+                for (int k = 0; k < order; ++k) same = same && h[j - k] == h[n - 1 - k];
+                if (same) return h[j + 1];
+            }
+        }
+        return h[n - 1];
+    }
     nik_map* map = nullptr;                  // optional (borrowed): keyframes are added to it and searched for loops
     int to_find_loop = 0;
     // MapBuilder::_loop_matches: loops found at CONSECUTIVE keyframes; a keyframe without a loop triggers CheckAndOptimize
@@ -274,6 +293,12 @@ int nik_tracker_speculation(const nik_tracker* t, long out[3]) {
     return NIK_OK;
 }
 
+// the tracker's guess of the next keyframe gap from a history of gaps (oldest first); exported for the tests
+int nik_tracker_guess_gap(const int32_t* gaps, int n) {
+    if (!gaps || n <= 0) return 0;
+    return nik_tracker::guess_next_gap(std::vector<int>(gaps, gaps + n));
+}
+
 int nik_tracker_poses(const nik_tracker* t, int32_t* frame_ids, double* poses, int cap, int* n) {
     if (!t || !n) return NIK_ERR_INVALID_ARG;
     *n = (int)t->kf_ids.size();
@@ -337,26 +362,40 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
         // little work is thrown away while the batches stay as large as the sequence allows.
         //
         // Key-frame chains.  Every keyframe switch would otherwise cost one host round trip of a small, latency-bound batch
-        // (~0.1 ms whatever its size below 16 pairs).  When the spacing has been regular (gap g), the frame that becomes the
-        // next keyframe is probably frame start + g - 1: the SAME batch therefore also registers the frames behind that
-        // guess against it (every frame's spectra are resident: any frame can serve as a key), and so on for up to
-        // spec_chain further guesses.  A guess that turns out right saves the round trip; a wrong one costs its few pairs of
-        // GPU work.  Outputs are exactly those of sequential calls: a speculative result is used only if its key is the
-        // frame the reference's rule really inserted.
+        // (~0.1 ms whatever its size below 16 pairs).  The gaps between keyframes are guessed from their own history
+        // (guess_next_gap: regular spacing and short periodic patterns): the SAME batch also registers the frames behind the
+        // guessed next keyframe against it (every frame's spectra are resident: any frame can serve as a key), and behind the
+        // one guessed after that, and so on while the batch has room.  A guess that turns out right saves the round trip; a
+        // wrong one costs its few pairs of GPU work.  Outputs are exactly those of sequential calls: a speculative result is
+        // used only if its key is the frame the reference's rule really inserted.
         segs.clear();
         int total = 0;
-        const int depth = std::max(1, t->spec_depth);
+        std::vector<int> hist = t->gap_hist;
+        int guess = nik_tracker::guess_next_gap(hist);             // frames from the current keyframe to the next one (0: no history)
+        // first segment: the frames behind the current keyframe, twice as far as the next keyframe is expected
+        const int depth = std::max(1, guess > 0 ? std::max(4, 2 * guess) : t->spec_depth);
         { const int m0 = std::min({ n - start, depth, t->max_batch });
           for (int i = 0; i < m0; ++i) { keys[i] = t->key_slot; curs[i] = slot[start + i]; }
           segs.push_back({ -1, start, m0, 0 }); total = m0; }
-        if (t->last_gap > 0) {
-            int kidx = start + t->last_gap - 1;
-            for (int c = 0; c < t->spec_chain && kidx < n - 1 && kidx < start + segs[0].count; ++c, kidx += t->last_gap) {
-                const int first = kidx + 1, ms = std::min({ n - first, depth, t->max_batch - total });
+        if (guess > 0) {
+            // frames since the current keyframe that were consumed by earlier calls count towards the gap
+            int kidx = start + guess - 1 - (t->frame_id - 1 - t->key_frame_id);
+            // a guess costs its few registrations, a round trip saved is worth ~25 of them: keep guessing as long as one
+            // guess in four holds; otherwise a single probe per call keeps the rate measured
+            const int max_chain = t->guess_rate >= 0.25 ? 16 : 1;
+            // (the first guessed keyframe must be one of the frames the first segment registers -- that is what confirms it; every
+            // later one is the last frame of the segment before it)
+            for (int c = 0; c < max_chain && kidx >= start && kidx < n - 1 && (c > 0 || kidx < start + segs[0].count); ++c) {
+                hist.push_back(guess);
+                const int next = std::max(1, nik_tracker::guess_next_gap(hist));
+                const int first = kidx + 1;
+                // up to and including the next guessed keyframe; the chain's last segment could go on to twice that
+                int ms = std::min({ n - first, next, t->max_batch - total });
                 if (ms <= 0) break;
                 for (int i = 0; i < ms; ++i) { keys[total + i] = slot[kidx]; curs[total + i] = slot[first + i]; }
                 segs.push_back({ kidx, first, ms, total }); total += ms;
-                if (kidx + t->last_gap >= first + ms) break;      // the next guess would lie beyond what this segment registers
+                if (ms < next) break;                          // out of frames or of batch room: the next guess is not covered
+                guess = next; kidx += next;
             }
         }
         if ((rc = nik_pose_batch(t->ctx, total, keys.data(), curs.data(), 1, res.data()))) return bail(rc);
@@ -370,16 +409,18 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
             start = S.first + i;
             if (inserted) {
                 t->last_gap = std::max(1, t->key_frame_id - prev_key_frame);
+                t->gap_hist.push_back(t->last_gap);
+                if (t->gap_hist.size() > 96) t->gap_hist.erase(t->gap_hist.begin());
                 t->spec_depth = std::min(t->max_batch, std::max(4, 2 * t->last_gap));
             } else {
                 t->spec_depth = std::min(t->max_batch, 2 * std::max(1, t->spec_depth));
             }
             // the next segment is usable iff its guessed key is the frame that has just been inserted
-            if (inserted && sg + 1 < segs.size() && segs[sg + 1].key_idx == start - 1) { ++sg; t->spec_hits += 1; continue; }
-            if (sg + 1 < segs.size()) t->spec_misses += 1;
-            // the chain grows while the guesses hold and collapses when one fails
-            if (inserted && (segs.size() == 1 || sg + 1 == segs.size())) t->spec_chain = std::min(6, t->spec_chain + 1);
-            else if (sg + 1 < segs.size()) t->spec_chain = 0;
+            if (inserted && sg + 1 < segs.size() && segs[sg + 1].key_idx == start - 1) {
+                ++sg; t->spec_hits += 1; t->guess_rate = 0.9 * t->guess_rate + 0.1;
+                continue;
+            }
+            if (sg + 1 < segs.size()) { t->spec_misses += 1; t->guess_rate = 0.9 * t->guess_rate; }
             break;
         }
     }

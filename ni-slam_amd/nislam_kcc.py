@@ -31,7 +31,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
            "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
-           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
+           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_guess_gap", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
            "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_rgb_to_gray_async", "nik_group_shard", "nik_group_pick_best", "nik_group_comm_ranks",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
@@ -144,6 +144,7 @@ def load():
         L.nik_tracker_loops.argtypes = [P, P, I, P]
         L.nik_tracker_pending_loops.argtypes = [P]
         L.nik_tracker_speculation.argtypes = [P, P]
+        L.nik_tracker_guess_gap.argtypes = [P, I]
         L.nik_tracker_poses.argtypes = [P, P, P, I, P]
         L.nik_tracker_edges.argtypes = [P, P, P, I, P]
         L.nik_tracker_optimizations.argtypes = [P, P]
@@ -672,6 +673,12 @@ def tracker_config(fx=600.0, fy=600.0, cx=320.0, cy=240.0, height=0.1, max_dista
     for i, v in enumerate([1, 0, 0, 0, 1, 0, 0, 0, 1]):
         cfg.extrinsics[i] = float(v)
     return cfg
+
+
+def tracker_guess_gap(gaps):
+    """the next keyframe gap nik_tracker_push_dev would guess after `gaps` (oldest first)"""
+    g = _i32(gaps)
+    return int(load().nik_tracker_guess_gap(_p(g), len(g)))
 
 
 class Tracker:

@@ -34,6 +34,23 @@ def test_se2_helpers():
     assert normalize_angle(math.pi) == pytest.approx(-math.pi)
 
 
+def test_keyframe_gap_guess():
+    """the history-based guess behind push_dev's keyframe chains (host code, no GPU): regular spacing, periodic patterns with an
+    irregular beat (bench.py's saw-tooth path: 6, 3, ... with 3, 3, 6, 1 every 64 frames), and the fallbacks"""
+    N = nik()
+    g = N.tracker_guess_gap
+    assert g([]) == 0 and g([5]) == 5 and g([4, 4, 4]) == 4
+    assert g([6, 3, 6, 3, 6]) == 3 and g([6, 3, 6, 3]) == 6
+    assert g([2, 7]) == 7                                     # nothing to match: the last gap again
+    period = [6, 3] * 7 + [3, 6, 1]                           # 64 frames
+    hist = period * 4
+    right = [g(hist[:k]) == hist[k] for k in range(len(hist))]
+    assert all(right[2 * len(period):])                       # two periods of history: every later gap is guessed right
+    assert sum(right[len(period):2 * len(period)]) >= len(period) // 2     # one period: the places behind the irregular beat are missed
+    # a change of rhythm is picked up after one occurrence
+    assert g([4, 4, 4, 9, 4, 4, 4]) == 9
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("geom,n,window", [pytest.param(SMALL, 24, 8, id="60x80"), pytest.param(FULL, 10, 5, id="480x640")])
 def test_tracker_matches_reference_logic(geom, n, window):
@@ -177,6 +194,8 @@ def test_keyframe_chain_speculation_changes_nothing():
     n_key = sum(o["inserted"] for o in got)
     assert 8 <= n_key < n - 8, n_key
     assert held >= 4 and held > failed, (held, failed)
-    assert calls <= n_key - held + n // window, (calls, n_key, held)         # every guess that held saved one batched call (a push may end mid-segment)
+    # every guess that held saved one batched call; a push may end mid-segment, and a guessed gap that turns out too short leaves
+    # a segment without its keyframe (one more call)
+    assert calls <= n_key - held + n // window + failed and calls < n_key, (calls, n_key, held, failed)
     assert trk1.speculation()[0] == 0
     trk.close(); trk1.close(); flow.close(); flow1.close()
