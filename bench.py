@@ -381,7 +381,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     # property check (size-independent): pushing the frames one by one gives the same decisions as the speculative windows
     parity = None
     if args.cpu_sample > 0:
-        ns = min(T, 96)
+        ns = min(T, 2048)                          # (every frame: a wrong keyframe guess that slipped through would show here)
         flow = N.CorrelationFlow(cfg, H, W, max_batch=1, max_frames=ns + 3, device=local_rank)
         flow.set_kzz_cache(True)
         trk = N.Tracker(flow, N.tracker_config())

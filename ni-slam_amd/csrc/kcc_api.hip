@@ -104,6 +104,7 @@ struct nik_ctx {
     int16_t* ud_map1 = nullptr; uint16_t* ud_map2 = nullptr;   // undistortion maps (nik_set_undistort); null = u8 inputs are already undistorted
     bool zz_half = true;          // uncached Kzz: transform only the Hermitian half of its kernel plane ($NIK_ZZ_HALF=0: off)
     bool fuse_polar = true;       // tracking path: fuse the polar spectrum's last pass into the pose's first kernel ($NIK_FUSE_POLAR=0: off)
+    bool fuse_fix_zero = true;    // RemoveZeroComponent inside the shifted inverse kernel ($NIK_FUSE_FIX_ZERO=0: its own launch)
     bool alt_order = true;        // consecutive kernels of a lane walk the items in opposite directions ($NIK_ALT_ORDER=0: off)
     int chunk_pairs = 0;          // batched calls are cut into chunks of at most this many pairs, dealt to the lanes in turn (0: one chunk per lane; $NIK_CHUNK)
     float2* arena_KzF = nullptr; float2* arena_KzP = nullptr; unsigned* arena_MzF = nullptr; unsigned* arena_MzP = nullptr;
@@ -489,8 +490,9 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
       launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
                            L.gbuf, c->spec_max, need); }
     { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need); }
-    launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
+      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need, c->fuse_fix_zero); }
+    // RemoveZeroComponent: inside that kernel (mirrored half-plane form), else a launch of its own
+    if (!(need > 0 && c->fuse_fix_zero)) launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
     { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar", a_tag(c, P)).c_str(), n * (Rb(I) + Cb(P)));
       launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max); }
     if (defer_polar_B) return;
@@ -725,6 +727,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
     if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
     if (const char* e = getenv("NIK_ALT_ORDER")) c->alt_order = atoi(e) != 0;
+    if (const char* e = getenv("NIK_FUSE_FIX_ZERO")) c->fuse_fix_zero = atoi(e) != 0;
     if (const char* e = getenv("NIK_CHUNK")) c->chunk_pairs = std::max(0, atoi(e));
     if (const char* e = getenv("NIK_GRAPH")) c->graph_max = std::max(0, atoi(e));
     c->slot_kind.assign(max_frames, 0);

@@ -121,9 +121,10 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
                        float* dst, size_t dst_stride);
 // inverse, /(rows*cols), written fftshift-ed into the zero-bordered planes S (column pitch rows+2).
 // need_cols > 0: the plane is real and even (the zero-phase image) and only its columns |c| <= need_cols are consumed:
-// transform the column tiles covering [0, min(W/2, need_cols)] and write each column's mirror too; 0 = the whole plane
+// transform the column tiles covering [0, min(W/2, need_cols)] and write each column's mirror too; 0 = the whole plane.
+// fix_zero (only with need_cols > 0): RemoveZeroComponent applied on the way -- the plane launch_fix_zero would leave
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride, int need_cols = 0);
+                          float* S, size_t s_stride, int need_cols = 0, bool fix_zero = false);
 // RemoveZeroComponent patch of the shifted planes (one workgroup per item)
 void launch_fix_zero(hipStream_t s, int n_items, float* S, size_t s_stride, int H, int W);
 // item order of the A / B kernels launched next by this host thread: 0 = front to back, 1 = back to front (speed only)

@@ -431,6 +431,7 @@ struct AArgs {
     float* real_out; size_t real_stride;
     Partial* partials; int partial_stride;
     const int* win_row; const int* win_col; int win_radius, win_mirror;   // ARGMAX_WIN: per-item window centre; mirror: also centre + rows/2
+    int fix_zero;                                            // SHIFTED (mirrored half-plane form): apply RemoveZeroComponent on the way
     KernelFn fn; unsigned* maxbuf; const float* energy;      // maxbuf: per-wave running-max parts [item][2][KCC_MAXPARTS] (float bits)
 };
 
@@ -1016,13 +1017,43 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
 
     if (EPI == EPI_SHIFTED) {
         // write fftshift(p) into the zero-bordered plane S (column pitch rows+2): out(r,c) at ((r+H/2)%H, (c+W/2)%W)
-        // (circ_shift.h:238-244); RemoveZeroComponent's row/column are patched afterwards by k_fix_zero.
+        // (circ_shift.h:238-244).  RemoveZeroComponent (correlation_flow.cc:79-87) is applied on the way when the launcher asks
+        // for it (fix_zero; needs the mirrored half-plane form): column 0 becomes (p(r,1) + p(r,W-1))/2 from the ORIGINAL
+        // columns -- p(r,W-1) is p(-r,1), and column 1 sits in the same tile as column 0 --, then row 0 of every other column
+        // becomes (p(1,c) + p(H-1,c))/2: the values k_fix_zero computes from the stored plane, without its launch.
         const int xcol = x0 + line;
         const bool half = a.zz_tiles > 0;                    // columns > W/2 come from their mirrors
+        constexpr int H = 2 * HH, SP = H + 2, HQ = H / 2;
+        float v0[DI::RL], v1[DI::RL];
+#pragma unroll
+        for (int q = 0; q < DI::RL; ++q) { v0[q] = vout[0][q].x * rsize; v1[q] = vout[0][q].y * rsize; }
+        if (a.fix_zero && half) {                            // (uniform)
+            float* sf = reinterpret_cast<float*>(lds);       // [0, H): column 1;  [H, H + LX): row H-1 of every column of the tile
+            __syncthreads();                                 // exchange buffers consumed
+            if (j < DI::ML) {
+                if (xcol == 1) {
+#pragma unroll
+                    for (int q = 0; q < DI::RL; ++q) { const int r = 2 * j + 2 * q * DI::ML; sf[r] = v0[q]; sf[r + 1] = v1[q]; }
+                }
+                if (j == DI::ML - 1) sf[H + line] = v1[DI::RL - 1];
+            }
+            __syncthreads();
+            if (j < DI::ML) {
+                if (xcol == 0) {
+#pragma unroll
+                    for (int q = 0; q < DI::RL; ++q) {
+                        const int r = 2 * j + 2 * q * DI::ML;
+                        v0[q] = (sf[r] + sf[r == 0 ? 0 : H - r]) * 0.5f;
+                        v1[q] = (sf[r + 1] + sf[H - r - 1]) * 0.5f;
+                    }
+                } else if (j == 0) {
+                    v0[0] = (v1[0] + sf[H + line]) * 0.5f;
+                }
+            }
+        }
         if (j < DI::ML && !(half && xcol > a.cols / 2)) {
             // H is the template's: with 0 <= j < ML known, the cyclic wraps below fold to constants for all but the one or
             // two q whose rows straddle H/2 (this epilogue was 60 % integer work with a run-time H)
-            constexpr int H = 2 * HH, SP = H + 2, HQ = H / 2;
             __builtin_assume(j >= 0); __builtin_assume(j < DI::ML);
             const int W = a.cols;
             int xs = xcol + W / 2; if (xs >= W) xs -= W;
@@ -1036,15 +1067,14 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
             for (int q = 0; q < DI::RL; ++q) {
                 const int r = 2 * j + 2 * q * DI::ML;
                 const int ys = r >= HQ ? r - HQ : r + HQ;
-                const float v0 = vout[0][q].x * rsize, v1 = vout[0][q].y * rsize;
-                if (HQ & 1) { col[ys] = v0; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1; }
-                else *reinterpret_cast<cf2*>(col + ys) = mk2(v0, v1);
+                if (HQ & 1) { col[ys] = v0[q]; col[ys + 1 >= H ? ys + 1 - H : ys + 1] = v1[q]; }
+                else *reinterpret_cast<cf2*>(col + ys) = mk2(v0[q], v1[q]);
                 if (mirror) {
                     // rows -r and -(r+1) sit at y0 = (HQ - r) mod H and y0 - 1: neighbours in memory except across the
                     // cyclic seam (r == HQ), so one 8-byte store
                     const int y0 = r > HQ ? 3 * HQ - r : HQ - r;
-                    if (r == HQ) { colm[0] = v0; colm[H - 1] = v1; }
-                    else { f2u pr; pr.x = v1; pr.y = v0; *reinterpret_cast<f2u*>(colm + y0 - 1) = pr; }
+                    if (r == HQ) { colm[0] = v0[q]; colm[H - 1] = v1[q]; }
+                    else { f2u pr; pr.x = v1[q]; pr.y = v0[q]; *reinterpret_cast<f2u*>(colm + y0 - 1) = pr; }
                 }
             }
         }
@@ -1288,10 +1318,11 @@ void launch_A_inv_real(hipStream_t s, int n_items, PlaneGeom g, Tables t, const 
 #undef CALL
 }
 void launch_A_inv_shifted(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,
-                          float* S, size_t s_stride, int need_cols) {
+                          float* S, size_t s_stride, int need_cols, bool fix_zero) {
     AArgs a = base_args(g, t);
     a.spec = const_cast<float2*>(src); a.spec_stride = src_stride; a.real_out = S; a.real_stride = s_stride;
     a.zz_tiles = need_cols > 0 ? need_cols + 1 : 0;          // (the launcher turns "columns <= need" into the tile count)
+    a.fix_zero = (fix_zero && need_cols > 0) ? 1 : 0;
 #define CALL(HH) launchA_inv_t<HH, EPI_SHIFTED>(s, n_items, 1, a)
     DISPATCH_HALF(g.rows / 2, CALL)
 #undef CALL

@@ -241,3 +241,30 @@ def test_scheduling_knobs_do_not_change_results():
     want = ((rgb[..., 0].astype(np.int64) * 4899 + rgb[..., 1].astype(np.int64) * 9617 + rgb[..., 2].astype(np.int64) * 1868 + 8192) >> 14).astype(np.uint8)
     assert np.array_equal(g1.cpu().numpy(), want) and np.array_equal(g2.cpu().numpy(), want)
     cf.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geom", [kcc_helpers.SMALL, kcc_helpers.FULL, dict(H=120, W=160, PD=240, PC=160)], ids=["60x80", "480x640", "120x160"])
+def test_fused_remove_zero_component_is_bit_identical(geom, monkeypatch):
+    """RemoveZeroComponent (correlation_flow.cc:79-87) runs inside the shifted inverse kernel by default; with
+    NIK_FUSE_FIX_ZERO=0 it is the separate k_fix_zero launch it used to be.  Same polar spectra, bit for bit (the image
+    spectrum does not depend on it), and the polar spectrum matches the oracle either way."""
+    N = nik()
+    H, W = geom["H"], geom["W"]
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    frames = [synth.make_pair(40 + i, H, W, 2 + i, -3, 1.5 * i)[1] for i in range(3)]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NIK_FUSE_FIX_ZERO", mode)
+        cf = N.CorrelationFlow(cfg, H, W, max_batch=4, max_frames=8)
+        for i, f in enumerate(frames):
+            cf.intermedium_u8(f, i)
+        got[mode] = [cf.frame_export(i) for i in range(len(frames))]
+        cf.close()
+    for a, b in zip(got["1"], got["0"]):
+        assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    from oracle import kcc_oracle as ko
+    orc = ko.Oracle(ko.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"]), H, W)
+    _, rp = orc.intermedium(orc.normalize_u8(frames[0]))
+    p = got["1"][0][2]
+    assert np.abs(p - rp).max() / np.abs(rp).max() < 2e-5
