@@ -400,7 +400,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
                  parity_spot_check=parity, roofline=None, cpu_baseline=None,
                  hipgraph={"frames_per_s_off": round(T / best_off, 1), "frames_per_s_on": round(T / best_g, 1),
                            "identical_outputs": bool(graphs_same), "reported": "on" if use_g else "off"},
-                 note="latency-bound: a keyframe switch is a dependent round trip of a small batch unless the tracker guessed the new keyframe (regular spacing) and registered the frames behind it in the same batch")
+                 note="a keyframe switch is a dependent round trip of a small batch unless the tracker guessed the new keyframe from the history of gaps and registered the frames behind it in the same batch (nik_tracker_guess_gap); all outputs equal one-frame-at-a-time pushes")
 
 
 def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
@@ -415,6 +415,10 @@ def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
     for k in range(args.warmup):
         pyr.track_dev_async(dk.data_ptr(), dc.data_ptr(), B, R, res=ring[k % 3])
     pyr.synchronize()
+    # (a batch takes ~1.3 ms from its first launch to its last result while a new one starts every ~0.8 ms: time at least 100 of
+    # them, or the drain of the pipeline at the end is 8 % of the measurement)
+    import copy
+    args = copy.copy(args); args.steps = max(args.steps, 100)
     t0 = time.perf_counter()
     for k in range(args.steps):
         raw = pyr.track_dev_async(dk.data_ptr(), dc.data_ptr(), B, R, res=ring[k % 3])
