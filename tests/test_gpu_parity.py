@@ -218,6 +218,28 @@ def test_gaussian_kernel_parity(geom):
     cf.close()
 
 
+@pytest.mark.parametrize("geom", GEOMS)
+@pytest.mark.parametrize("power", [1, 2, 5])
+def test_polynomial_kernel_other_powers(geom, power):
+    """cfg.power != 3 (correlation_flow.cc:213: (xz + offset).pow(power), Eigen's integer-exponent pow evaluated in double): the
+    general-power epilogue of the kernel plane against the oracle, both ComputePose modes, with and without the Kzz cache"""
+    n = 4
+    cf, orc, ocfg = _mk(geom, max_batch=n, max_frames=2 * n, power=power)
+    keys, curs, _ = _pairs(geom, n, 700 + power)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    for small_rot in (True, False):
+        poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, small_rot)
+        for cache in (False, True):
+            cf.set_kzz_cache(cache)
+            res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), small_rot)
+            for i in range(n):
+                ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], geom["PD"], psr_rtol=5e-3)
+                assert ok, (power, small_rot, cache, msg)
+    cf.close()
+
+
 def test_error_behaviour():
     N = nik()
     # invalid kernel id: the reference throws std::invalid_argument at EstimateTrans time (correlation_flow.cc:167-168)
