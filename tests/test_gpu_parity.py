@@ -240,6 +240,31 @@ def test_polynomial_kernel_other_powers(geom, power):
     cf.close()
 
 
+@pytest.mark.parametrize("kernel,lam,offset,sigma", [(0, 0.01, 0.1, 0.2), (0, 1.0, 1.0, 0.2), (0, 0.1, 0.0, 0.2), (1, 0.1, 0.1, 0.5), (1, 0.02, 0.1, 0.1)],
+                         ids=["poly-lambda0.01", "poly-lambda1-offset1", "poly-offset0", "gauss-sigma0.5", "gauss-sigma0.1-lambda0.02"])
+def test_other_config_values(kernel, lam, offset, sigma):
+    """CFConfig values other than config_ntu.yaml's (lambda, offset, sigma: read_configs.h:15-25) reach the kernels and match
+    the oracle"""
+    N = nik()
+    geom, n = SMALL, 4
+    cfg = N.default_config(kernel=kernel, rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    ocfg = ko.default_config(kernel=kernel, rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    for c in (cfg, ocfg):
+        c.lambda_, c.offset, c.sigma = lam, offset, sigma
+    cf = N.CorrelationFlow(cfg, geom["H"], geom["W"], max_batch=n, max_frames=2 * n)
+    keys, curs, _ = _pairs(geom, n, 900)
+    for i in range(n):
+        cf.intermedium_u8(keys[i], i)
+        cf.intermedium_u8(curs[i], n + i)
+    for small_rot in (True, False):
+        res = cf.pose_batch(list(range(n)), list(range(n, 2 * n)), small_rot)
+        poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, small_rot)
+        for i in range(n):
+            ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], geom["PD"], psr_rtol=1e-2)
+            assert ok, (small_rot, msg)
+    cf.close()
+
+
 def test_error_behaviour():
     N = nik()
     # invalid kernel id: the reference throws std::invalid_argument at EstimateTrans time (correlation_flow.cc:167-168)
