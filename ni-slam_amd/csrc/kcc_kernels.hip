@@ -146,8 +146,11 @@ __device__ __forceinline__ float kernel_value(const KernelFn& fn, float xz, floa
 // rev: walk the items back to front.  Consecutive kernels of a lane alternate the direction (set_launch_reverse), so a
 // consumer starts with the items its producer wrote LAST -- the ones still in the 256 MiB Infinity Cache
 // (tools/probes/mall_order_probe.hip: +22 % on a copy chain whose planes are about the cache's size).  Speed only.
+__device__ __forceinline__ void xcd_coords_of(int L, int nbx, int n_items, int& bx, int& item, int rev = 0);
 __device__ __forceinline__ void xcd_coords(int nbx, int n_items, int& bx, int& item, int rev = 0) {
-    const int L = blockIdx.x;
+    xcd_coords_of((int)blockIdx.x, nbx, n_items, bx, item, rev);
+}
+__device__ __forceinline__ void xcd_coords_of(int L, int nbx, int n_items, int& bx, int& item, int rev) {
     const int full_items = (n_items / 8) * 8;
     if (L < full_items * nbx) {
         const int xcd = L & 7, q = L >> 3;
@@ -417,6 +420,7 @@ struct AArgs {
     const float* src; size_t src_stride; const int* src_idx; int src_pitch;   // image planes: column pitch (>= rows, wrap rows behind)
     const int* rot_tab; const int* rot_index;              // per-angle int tables [adelta W | bdelta W | X0 H | Y0 H]
     int H, W, SP;                                            // polar source: shifted planes, column pitch SP
+    int polar_group;                                         // polar tiles per group (divides the tile count): see the kernel's block order
     const uint32_t* polar_chunks; const int* polar_seg_first; const uint4* polar_pts;   // staging descriptors / per-thread sample entries
     // u8 sources: SRC_U8 reads the batch input (row pitch src8_pitch) and copies its tile into the u8 frame store;
     // SRC_ROT8 reads the u8 frame store (row pitch src8_pitch = W + 16, columns 0..15 repeated behind column W-1)
@@ -676,9 +680,14 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
     if (POLAR) {
         // tile-major order, outermost (most expensive) ring first: the workgroups running at any time share one tile's
         // gather tables (L2-resident), and every item's annulus is read exactly once
-        const int nbx = a.cols / A_LX;
-        bx = nbx - 1 - (int)(blockIdx.x / (unsigned)a.n_items); item = (int)(blockIdx.x % (unsigned)a.n_items);
-        if (a.rev) item = a.n_items - 1 - item;
+        // ... in groups of a.polar_group neighbouring tiles: a tile's ring is only ~8 source pixels thick, so a 128-byte line of
+        // the source plane (32 pixels of a column) serves three or four neighbouring tiles -- run them back to back on the XCD
+        // that holds the line (the group's tables, polar_group x 92 KB, still fit its L2)
+        const int nbx = a.cols / A_LX, G = a.polar_group, per = G * a.n_items;
+        const int g = (int)blockIdx.x / per;
+        int tg;
+        xcd_coords_of((int)blockIdx.x - g * per, G, a.n_items, tg, item, a.rev);
+        bx = nbx - 1 - (g * G + tg);
     } else {
         xcd_coords(a.cols / A_LX, a.n_items, bx, item, a.rev);
     }
@@ -1228,8 +1237,18 @@ template <int HH, int EPI, int LXO = 0> static void launchA_inv_t(hipStream_t s,
 }
 
 // polar forward kernel for `qs` first-pass points per thread and segment (one of the sizes fwd_geom() offers)
-template <int HH> static void polar_launch(hipStream_t s, int n_items, const AArgs& a, int qs, size_t lds) {
+#ifndef KCC_POLAR_GROUP
+#define KCC_POLAR_GROUP 10
+#endif
+template <int HH> static void polar_launch(hipStream_t s, int n_items, const AArgs& a_in, int qs, size_t lds) {
     constexpr int RF = Dir<typename FCfg<HH>::P, false>::RF;
+    AArgs a = a_in;
+    // tiles per group: the largest divisor of the tile count that is <= the wanted group size ($NIK_POLAR_GROUP; 1 = tile-major)
+    static const int want = getenv("NIK_POLAR_GROUP") ? std::max(1, atoi(getenv("NIK_POLAR_GROUP"))) : KCC_POLAR_GROUP;
+    const int tiles = a.cols / FCfg<HH>::LX;
+    int G = std::min(want, tiles);
+    while (tiles % G) --G;
+    a.polar_group = G;
     if constexpr (RF % 2 == 0) { if (qs == RF / 2) { launchA_fwd_t<HH, SRC_POLAR_H>(s, n_items, a, lds); return; } }
     if constexpr (polar_qs_mid(RF) > 1) { if (qs == polar_qs_mid(RF)) { launchA_fwd_t<HH, SRC_POLAR_T>(s, n_items, a, lds); return; } }
     launchA_fwd_t<HH, SRC_POLAR_Q>(s, n_items, a, lds);
