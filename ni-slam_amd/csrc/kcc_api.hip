@@ -257,6 +257,7 @@ inline int* hidx(Lane& L, int which) { return L.cur->h_idx + (size_t)which * L.c
 // The device copy of an index array is left alone when it already holds these values (a tracker or a pyramid level that
 // works on the same slots call after call): one stream operation fewer per call, which is what small batches are bound by.
 // L.idx_shadow mirrors what the host has uploaded into d_idx[0, IX_ROTIDX) (the arrays behind are written by kernels).
+static_assert(IX_ROTIDX == 5, "Lane::idx_shadow_n and stage_pose_indices::used list the five host-filled index arrays");
 inline bool idx_unchanged(Lane& L, int which, int n) {
     return n <= L.idx_shadow_n[which] && memcmp(L.idx_shadow.data() + (size_t)which * L.cap_items, hidx(L, which), sizeof(int) * n) == 0;
 }
