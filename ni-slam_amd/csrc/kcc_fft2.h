@@ -156,8 +156,11 @@ template <> struct PlanFor<120> : Plan<120, 10, 12> {};
 #ifndef KCC_P240
 #define KCC_P240 16, 15
 #endif
+// (forward kernels of the 720-row planes: a 20-point first pass makes the u8 de-rotation's source bands 36 rows tall -- 3 LDS
+// pieces per box row instead of 5, three workgroups per CU instead of two at 1280x720 -- and suits the polar gather of that
+// geometry (-11 %); the spectrum-in kernels keep 18 x 20, PlanInv below)
 #ifndef KCC_P360
-#define KCC_P360 18, 20
+#define KCC_P360 20, 18
 #endif
 #ifndef KCC_P480
 #define KCC_P480 20, 24
@@ -200,9 +203,10 @@ template <int N> struct PlanInv : PlanFor<N> {};
 #ifdef KCC_PI240
 template <> struct PlanInv<240> : Plan<240, KCC_PI240> {};
 #endif
-#ifdef KCC_PI360
-template <> struct PlanInv<360> : Plan<360, KCC_PI360> {};
+#ifndef KCC_PI360
+#define KCC_PI360 18, 20
 #endif
+template <> struct PlanInv<360> : Plan<360, KCC_PI360> {};
 
 // Twiddle table layout (built on the host, see kcc_api.hip build_plan_tables):
 //   2 passes, direction d:  tw[q*RF + k] = W_N^(+-q*k),            q < RL, k < RF
