@@ -9,7 +9,7 @@ WL=${2:-pairs}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
 B=$([ "$WL" = hd ] && echo 128 || echo 256)
-python $R/tools/rocprof_summary.py $TAG $OUT $B -- python $R/bench.py --workload $WL --steps 6 --warmup 2 --cpu-sample 0 --no-profile --no-cached --no-live-prof
+python $R/tools/rocprof_summary.py $TAG $OUT $B -- python $R/bench.py --workload $WL --steps 40 --warmup 10 --cpu-sample 0 --no-profile --no-cached --no-live-prof
 # (gpurun merges gpurun_out/ back, not profiles/: copy gpurun_out/${TAG}_* into profiles/ afterwards)
 cd $R && python bench.py --workload $WL --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python -c "
