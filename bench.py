@@ -348,7 +348,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
         base = [synth.window(cv, H, W, int(3 * i) % 200 - 100, int(2 * i) % 160 - 80, 0.5 * (i % 9)) for i in range(64)]
     seq = np.stack([base[i % len(base)] for i in range(T)])
     d_seq = torch.from_numpy(seq).to(dev)
-    win = min(args.batch, 64)
+    win = min(args.batch, int(os.environ.get("NIK_SEQ_WINDOW", "64")))
     cfg = N.default_config()
 
     def run(nframes, graphs=0):
