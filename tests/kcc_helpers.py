@@ -42,9 +42,13 @@ def ang_diff(a, b):
 # constant IS that measured sum (the largest gap ever accepted in the 512 + 6144 + 2 x 3072 pair sweeps was 9.2e-4); the
 # test keeps it between 1x and 4x of what it measures.
 ROT_TIE_REL = 1.2e-3
+# The gaussian kernel multiplies the rounding error of xz by 2 / sigma^2 (= 50 at the reference's sigma 0.2) inside exp():
+# both float32 implementations sit correspondingly further from the float64 response, measured the same way
+# (tests/test_gpu_wide.py::test_response_noise_gaussian_kernel, profiles/r03_response_noise_gaussian.json).
+ROT_TIE_REL_GAUSS = 4.0e-3
 
 
-def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=None):
+def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=None, tie_rel=None):
     """gpu: dict from NikPoseResult.as_dict(); ora_*: oracle outputs.  Returns (ok, exact_rot, message).
 
     Rule: translation arg-max indices bit-exact; rotation arg-max bit-exact unless the oracle's own two
@@ -56,15 +60,16 @@ def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun
     IMPOSED at the GPU's position (Oracle.force_rotation).  It generalises the tie rule to any near-tie of the
     rotation surface (e.g. a true rotation halfway between two 0.5-degree bins): if the oracle's response at the
     GPU's position is within ROT_TIE_REL of the oracle's maximum, the GPU must match that imposed run exactly."""
+    tie_rel = ROT_TIE_REL if tie_rel is None else tie_rel
     exact_rot = gpu["rot_row"] == ora_dbg["rot_row"] and gpu["rot_col"] == ora_dbg["rot_col"]
     if not exact_rot:
         gap = abs(ora_dbg["rot_peak"] - ora_dbg["rot_mirror"]) / max(abs(ora_dbg["rot_peak"]), 1e-30)
         mirror = gpu["rot_col"] == ora_dbg["rot_col"] and (gpu["rot_row"] - ora_dbg["rot_row"]) % PD == PD // 2
-        if not (mirror and gap < ROT_TIE_REL):
+        if not (mirror and gap < tie_rel):
             if rerun is not None:
                 pose2, info2, dbg2 = rerun(gpu["rot_row"], gpu["rot_col"])
                 gap2 = (ora_dbg["rot_peak"] - dbg2["rot_peak"]) / max(abs(ora_dbg["rot_peak"]), 1e-30)
-                if gap2 < ROT_TIE_REL:
+                if gap2 < tie_rel:
                     ok, _, msg = _compare(gpu, pose2, info2, psr_rtol)
                     return ok, False, ("near-tie gap=%.2e: " % gap2) + msg
             ok, _, msg = _compare(gpu, ora_pose, ora_info, psr_rtol)

@@ -11,11 +11,12 @@ N = nik()
 H, W = 480, 640
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 max_theta = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
+kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # 0 polynomial, 1 gaussian
 B = 128
-cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=B, max_frames=2 * B)
-ocfg = ko.default_config()
+cf = N.CorrelationFlow(N.default_config(kernel=kernel), H, W, max_batch=B, max_frames=2 * B)
+ocfg = ko.default_config(kernel=kernel)
 ora = ko.Oracle(ocfg, H, W)
-out = {"pairs_per_mode": n, "max_theta_deg": max_theta}
+out = {"pairs_per_mode": n, "max_theta_deg": max_theta, "kernel": ["polynomial", "gaussian"][kernel]}
 for small in (True, False):
     exact = ties = near = fails = 0; worst_psr = 0.0; msgs = []
     for b0 in range(0, n, B):
@@ -35,7 +36,7 @@ for small in (True, False):
                 r = ora.compute_pose(kf, ci, kp, cp, small)
                 ora.force_rotation(-1, -1)
                 return r
-            ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], 720, rerun=rerun)
+            ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], 720, rerun=rerun, **({"psr_rtol": 1e-2, "tie_rel": __import__("kcc_helpers").ROT_TIE_REL_GAUSS} if kernel else {}))
             near += bool(ok and not ex and msg.startswith("near-tie"))
             exact += bool(ok and ex); ties += bool(ok and not ex and not msg.startswith("near-tie")); fails += (not ok)
             if ok and (ex or not msg.startswith("near-tie")):
