@@ -110,7 +110,10 @@ class Oracle:
 
     def __del__(self):
         if getattr(self, "_ctx", None):
-            lib().ora_destroy(self._ctx)
+            try:
+                lib().ora_destroy(self._ctx)
+            except TypeError:                  # interpreter shutdown: the module globals are gone already
+                pass
             self._ctx = None
 
     def force_rotation(self, row=-1, col=-1):

@@ -8,7 +8,7 @@ import numpy as np, torch, synth
 from kcc_helpers import check_pose_parity, nik
 from oracle import kcc_oracle as ko
 N = nik()
-H, W = 480, 640
+H, W = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (480, 640)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 max_theta = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # 0 polynomial, 1 gaussian
@@ -16,7 +16,7 @@ B = 128
 cf = N.CorrelationFlow(N.default_config(kernel=kernel), H, W, max_batch=B, max_frames=2 * B)
 ocfg = ko.default_config(kernel=kernel)
 ora = ko.Oracle(ocfg, H, W)
-out = {"pairs_per_mode": n, "max_theta_deg": max_theta, "kernel": ["polynomial", "gaussian"][kernel]}
+out = {"pairs_per_mode": n, "max_theta_deg": max_theta, "kernel": ["polynomial", "gaussian"][kernel], "H": H, "W": W}
 for small in (True, False):
     exact = ties = near = fails = 0; worst_psr = 0.0; msgs = []
     for b0 in range(0, n, B):
