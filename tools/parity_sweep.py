@@ -21,7 +21,7 @@ for small in (True, False):
     exact = ties = near = fails = 0; worst_psr = 0.0; msgs = []
     for b0 in range(0, n, B):
         m = min(B, n - b0)
-        keys, curs, _ = synth.make_batch(m, H, W, seed0=50000 + b0 + (0 if small else 10 ** 6), max_shift=48, max_theta=max_theta)
+        keys, curs, _ = synth.make_batch(m, H, W, seed0=50000 + b0 + (0 if small else 10 ** 6), max_shift=int(os.environ.get("NIK_SWEEP_SHIFT", "48")), max_theta=max_theta)
         dk = torch.from_numpy(keys).cuda(); dc = torch.from_numpy(curs).cuda(); torch.cuda.synchronize()
         cf.intermedium_batch_dev(dk.data_ptr(), m, list(range(m)))
         res = cf.track_batch_dev(dc.data_ptr(), list(range(m)), list(range(B, B + m)), small, sync=True)
