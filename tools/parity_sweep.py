@@ -13,15 +13,23 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 max_theta = float(sys.argv[2]) if len(sys.argv) > 2 else 10.0
 kernel = int(sys.argv[3]) if len(sys.argv) > 3 else 0        # 0 polynomial, 1 gaussian
 B = 128
+# float32 noise of the translation response (oracle 6.6e-3 + HIP 6.0e-3 of the peak against float64, profiles/r03_response_noise.json):
+# two positions of the oracle's own surface closer than this can swap between float32 implementations
+TRANS_TIE_REL = 1.3e-2
 cf = N.CorrelationFlow(N.default_config(kernel=kernel), H, W, max_batch=B, max_frames=2 * B)
 ocfg = ko.default_config(kernel=kernel)
 ora = ko.Oracle(ocfg, H, W)
 out = {"pairs_per_mode": n, "max_theta_deg": max_theta, "kernel": ["polynomial", "gaussian"][kernel], "H": H, "W": W}
 for small in (True, False):
-    exact = ties = near = fails = 0; worst_psr = 0.0; msgs = []
+    exact = ties = near = fails = trans_near = 0; worst_psr = 0.0; msgs = []; trans_ties = []; kinds = {}
     for b0 in range(0, n, B):
         m = min(B, n - b0)
         keys, curs, _ = synth.make_batch(m, H, W, seed0=50000 + b0 + (0 if small else 10 ** 6), max_shift=int(os.environ.get("NIK_SWEEP_SHIFT", "48")), max_theta=max_theta)
+        if int(os.environ.get("NIK_SWEEP_BLUR", "0")) > 1:            # smooth content: broad correlation peaks
+            from scipy.ndimage import uniform_filter
+            k = int(os.environ["NIK_SWEEP_BLUR"])
+            keys = np.stack([uniform_filter(f.astype(np.float32), k, mode="wrap").round().astype(np.uint8) for f in keys])
+            curs = np.stack([uniform_filter(f.astype(np.float32), k, mode="wrap").round().astype(np.uint8) for f in curs])
         dk = torch.from_numpy(keys).cuda(); dc = torch.from_numpy(curs).cuda(); torch.cuda.synchronize()
         cf.intermedium_batch_dev(dk.data_ptr(), m, list(range(m)))
         res = cf.track_batch_dev(dc.data_ptr(), list(range(m)), list(range(B, B + m)), small, sync=True)
@@ -41,6 +49,20 @@ for small in (True, False):
             exact += bool(ok and ex); ties += bool(ok and not ex and not msg.startswith("near-tie")); fails += (not ok)
             if ok and (ex or not msg.startswith("near-tie")):
                 worst_psr = max(worst_psr, max(abs(g["info"][k] - infos[i][k]) / abs(infos[i][k]) for k in (0, 2)))
+            if not ok and "translation" in msg and "rot argmax" not in msg:
+                # smooth content: is the GPU's translation arg-max a float32 near-tie of the ORACLE's own surface?  (the gap between
+                # the oracle's maximum and its value at the GPU's position, against the measured float32 noise of that surface)
+                cg, co = g["chosen"], dbgs[i]["chosen"]
+                x = ora.normalize_u8(curs[i]); kf, kp = ora.intermedium(ora.normalize_u8(keys[i]))
+                xr = ora.fft(ora.rotate(x, dbgs[i]["degree_used"][co]))
+                _, _, rt, ct, g_o = ora.estimate_trans(kf, xr, 0, want_g=True)
+                gap = float(g_o[ct, rt] - g_o[g["trans_col"][cg], g["trans_row"][cg]]) / float(g_o[ct, rt])
+                d = max(abs(g["trans_row"][cg] - rt), abs(g["trans_col"][cg] - ct))
+                trans_ties.append((round(gap, 6), int(d)))
+                if gap < TRANS_TIE_REL: fails -= 1; trans_near += 1; ok = True
+            if not ok:
+                kind = "rotation" if "rot argmax" in msg else ("translation" if "translation" in msg else ("psr_only" if "info[" in msg and "theta" not in msg else "other"))
+                kinds[kind] = kinds.get(kind, 0) + 1
             if not ok and len(msgs) < 5: msgs.append("pair %d: %s" % (b0 + i, msg))
-    out["small_rot" if small else "large_rot"] = {"exact": exact, "mirror_tie_accepted": ties, "other_near_tie_verified": near, "failed": fails, "worst_psr_rel_err": round(worst_psr, 6), "first_failures": msgs}
+    out["small_rot" if small else "large_rot"] = {"exact": exact, "mirror_tie_accepted": ties, "other_near_tie_verified": near, "translation_near_tie_verified": trans_near, "translation_near_ties(gap,pixels)": trans_ties[:40], "failed": fails, "failed_by_kind": kinds, "worst_psr_rel_err": round(worst_psr, 6), "first_failures": msgs}
 print(json.dumps(out))
