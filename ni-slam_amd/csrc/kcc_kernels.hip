@@ -683,10 +683,11 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
         // ... in groups of a.polar_group neighbouring tiles: a tile's ring is only ~8 source pixels thick, so a 128-byte line of
         // the source plane (32 pixels of a column) serves three or four neighbouring tiles -- run them back to back on the XCD
         // that holds the line (the group's tables, polar_group x 92 KB, still fit its L2)
-        const int nbx = a.cols / A_LX, G = a.polar_group, per = G * a.n_items;
-        const int g = (int)blockIdx.x / per;
+        const int nbx = a.cols / A_LX, G = a.polar_group, per = G * a.n_items, per8 = (per + 7) / 8 * 8;
+        const int g = (int)blockIdx.x / per8, loc = (int)blockIdx.x - g * per8;
+        if (loc >= per) return;                              // padding of the group to a multiple of 8 blocks
         int tg;
-        xcd_coords_of((int)blockIdx.x - g * per, G, a.n_items, tg, item, a.rev);
+        xcd_coords_of(loc, G, a.n_items, tg, item, a.rev);
         bx = nbx - 1 - (g * G + tg);
     } else {
         xcd_coords(a.cols / A_LX, a.n_items, bx, item, a.rev);
@@ -1208,6 +1209,12 @@ int kfwd_parts(PlaneGeom g, bool half) {
 template <int HH, int SRC> static void launchA_fwd_t(hipStream_t s, int n_items, AArgs a, size_t min_lds = 0) {
     a.n_items = n_items;
     dim3 grid((a.cols / FCfg<HH>::LX) * n_items), block(FCfg<HH>::NT);
+    if (SRC == SRC_POLAR_H || SRC == SRC_POLAR_Q || SRC == SRC_POLAR_T) {
+        // tile groups start on a multiple of 8 blocks, so that a block's place inside its group says which XCD it runs on
+        // (blocks go to the XCDs round-robin); the few blocks of padding return at once
+        const int G = a.polar_group, tiles = a.cols / FCfg<HH>::LX;
+        grid = dim3((unsigned)((tiles / G) * ((G * n_items + 7) / 8 * 8)));
+    }
     const size_t bytes = std::max(fwd_lds_bytes<HH, SRC>(), min_lds);
     static size_t lds_cap = 65536;                           // largest dynamic LDS size this instantiation may launch with
     if (bytes > lds_cap &&
