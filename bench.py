@@ -239,28 +239,55 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
     for _ in range(args.warmup):
         res = step()
     cf.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    cf.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+
+    def timed_region():
+        """EXACTLY args.steps steps between barrier + synchronize on both sides; returns this rank's seconds"""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = None
+        for _ in range(args.steps):
+            r = step()
+        cf.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0, r
+
+    # The timed region (K steps, ~50 ms at the defaults) is repeated -- the same K steps every time -- until a second of
+    # measurement has accumulated: one region alone cannot show a 3 % change (boxes and clock ramps differ by more).  The
+    # line reports the MEDIAN region (value, ms_per_step) and the fastest / slowest one next to it; with more than one rank
+    # every region's time is the MAX over the ranks.
+    cdev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+    region_max, region_own = [], []
+    n_rep = 1 if args.repeats == 1 else None
+    while True:
+        dt_own, res = timed_region()
+        dt_max = dt_own
+        if world > 1:
+            t = torch.tensor([dt_own], dtype=torch.float64, device=cdev)
+            allt = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(allt, t)
+            region_own.append([float(x.item()) for x in allt])
+            dt_max = max(region_own[-1])
+        else:
+            region_own.append([dt_own])
+        region_max.append(dt_max)
+        if n_rep is None:                        # number of repeats: fixed by the first region (identical on every rank)
+            n_rep = args.repeats if args.repeats > 0 else int(min(64, max(3, round(args.min_time / max(dt_max, 1e-6)))))
+        if len(region_max) >= n_rep:
+            break
+    order = sorted(range(len(region_max)), key=lambda i: region_max[i])
+    med = order[len(order) // 2]
+    dt = region_max[med]
     stats = grp.residual_result() if grp is not None else (stats_t.cpu().numpy() if stats_t is not None else None)
-    rank_rates = [B / (dt / args.steps)]
-    if world > 1:
-        cdev = dev if dist.get_backend() == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        allt = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(allt, t)
-        rank_rates = [B / (float(x.item()) / args.steps) for x in allt]          # every rank's own pairs/s over its own clock
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    rank_rates = [B / (x / args.steps) for x in region_own[med]]                 # every rank's own pairs/s over its own clock (median region)
     ms_per_step = 1e3 * dt / args.steps
+    timing = dict(regions=len(region_max), steps_per_region=args.steps, ms_per_step_median=round(ms_per_step, 4),
+                  ms_per_step_min=round(1e3 * min(region_max) / args.steps, 4), ms_per_step_max=round(1e3 * max(region_max) / args.steps, 4),
+                  value_max=round(B * world / (min(region_max) / args.steps), 1), value_min=round(B * world / (max(region_max) / args.steps), 1),
+                  note="value / ms_per_step are the median timed region of K steps; every region is bracketed by barrier + synchronize and is the MAX over ranks")
     pairs_per_s = B * world / (dt / args.steps)
     last = [r.as_dict() for r in res]                               # the final timed step's per-pair results (this rank)
 
@@ -317,7 +344,7 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
         out = _line(metric, "frame-pairs/s", pairs_per_s, world, args, ms_per_step, wl,
                     bpp, dict(pairs_per_gpu_per_step=B, unique_pairs=U, parallelism="pairs sharded x%d" % world, residual_allreduce=comm),
                     roofline=_roofline(kernels, B, live), cpu_baseline=cpu, parity_spot_check=parity_ok,
-                    residual_stats=None if stats is None else [float(v) for v in stats],
+                    residual_stats=None if stats is None else [float(v) for v in stats], timing=timing,
                     multi_gpu=dict(world=world, rccl_ranks=rccl_ranks, fallback=bool(fallback),
                                    pairs_per_s_per_rank_min=round(min(rank_rates), 1), pairs_per_s_per_rank_max=round(max(rank_rates), 1),
                                    note="rccl_ranks = ncclCommCount of the library's communicator (0: one GPU, no collective); fallback: the residual all-reduce ran through torch.distributed instead of nik_group"),
@@ -511,11 +538,31 @@ def main():
     ap.add_argument("--seq-rot-rate", type=float, default=0.25, help="sequence workload, smooth path: degrees per frame")
     ap.add_argument("--seq-motion", default="sawtooth", choices=["sawtooth", "smooth"], help="sequence workload: synthetic camera path")
     ap.add_argument("--candidates", type=int, default=4096, help="loop4096 workload: resident key frames")
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0 = as many as fill --min-time, 3..64); the line reports the median")
+    ap.add_argument("--min-time", type=float, default=1.0, help="seconds of timed regions to accumulate when --repeats is 0")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")
     ap.add_argument("--no-live-prof", action="store_true", help="skip the live rocprofv3 passes (durations + HBM bytes of the dominant kernel)")
     args = ap.parse_args()
     args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
+
+    # `python bench.py --gpus N` on its own starts the N ranks itself (one process per GPU under torch.distributed.run, the
+    # launcher the driver uses when it starts the ranks); under a launcher, --gpus must agree with the world it created.
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if env_world is None and args.gpus > 1:
+        if args.workload not in ("pairs", "hd"):
+            raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
+        port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("bench.py: --gpus %d without a launcher: starting %d ranks under torch.distributed.run\n" % (args.gpus, args.gpus))
+        sys.stderr.flush()
+        os.execv(sys.executable, cmd)
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher created WORLD_SIZE=%s ranks: refusing to report a line whose n_gpus is not what was asked for"
+                         % (args.gpus, env_world))
 
     import numpy as np
     import torch

@@ -349,6 +349,7 @@ typedef struct nik_pg_shard nik_pg_shard;
 int  nik_pg_shard_create(int device, int n_poses, const int32_t* ids, const double* poses, int n_constraints,
                          const nik_pg_constraint* constraints, nik_pg_shard** out);
 void nik_pg_shard_destroy(nik_pg_shard* s);
+int  nik_pg_shard_device(const nik_pg_shard* s);         /* the GPU the shard lives on (< 0: error) */
 int  nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses /* NULL: unchanged */, double** d_cost, void** stream);
 
 /* the tracker's pose graph: Map::_edges as OptimizeMap would feed them to the solver (robot units, identity information;

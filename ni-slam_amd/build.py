@@ -8,7 +8,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnislam_kcc_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-# -fno-slp-vectorize: packed FP32 (v_pk_*) buys no throughput on gfx950 and costs register shuffles (measured +9 %)
+# -fno-slp-vectorize: the FFT engine issues its packed FP32 (v_pk_*_f32 with op_sel / neg modifiers) through inline asm
+# (kcc_fft.h); what the SLP vectoriser packs on its own costs more in register shuffles than it saves (measured +9 %)
 UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_group.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
          ("kcc_camera.cpp", ["-ffp-contract=off"]), ("kcc_map.cpp", ["-ffp-contract=off"]),
          ("kcc_posegraph.cpp", ["-ffp-contract=off"]), ("kcc_posegraph_dev.hip", ["-ffp-contract=off"]), ("kcc_pyramid.cpp", ["-ffp-contract=off"]),

@@ -372,6 +372,9 @@ int nik_group_pose_graph_cost(nik_group* g, nik_pg_shard* const* shards, const d
     std::vector<hipStream_t> st(g->m.size(), nullptr);
     for (size_t i = 0; i < g->m.size(); ++i) {
         Member& mb = g->m[i];
+        // shards[i] must live on member i's GPU: the collective below runs on the shard's own stream
+        if (!shards[i] || nik_pg_shard_device(shards[i]) != mb.device)
+            return gfail(g, NIK_ERR_INVALID_ARG, "nik_group_pose_graph_cost: shard " + std::to_string(i) + " is not on its member's device");
         G_HIP(g, hipSetDevice(mb.device));
         void* s = nullptr;
         int rc = nik_pg_shard_cost_dev(shards[i], poses, &src[i], &s);

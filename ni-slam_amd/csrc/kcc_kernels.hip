@@ -205,12 +205,33 @@ __global__ __launch_bounds__(256) void k_cvt_u8(const uint8_t* __restrict__ src,
 }
 
 // cv::cvtColor(COLOR_RGB2GRAY / COLOR_BGR2GRAY) on 8-bit data: (R*4899 + G*9617 + B*1868 + 8192) >> 14  [recalled]
-__global__ void k_rgb2gray(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t npix, int bgr) {
+__device__ __forceinline__ unsigned luma8(unsigned r, unsigned g, unsigned b) { return (r * 4899u + g * 9617u + b * 1868u + 8192u) >> 14; }
+// 16 pixels per thread: three 16-byte loads (48 bytes of interleaved RGB), one 16-byte store -- the scalar form (one pixel
+// and three byte loads per thread) ran at 1.6 TB/s and was 8.8 % of every configs[3] step
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_rgb2gray16(const u32x4* __restrict__ rgb, u32x4* __restrict__ gray, size_t ngroups, int bgr) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ngroups) return;
+    const u32x4 a = __builtin_nontemporal_load(rgb + 3 * i), b = __builtin_nontemporal_load(rgb + 3 * i + 1), c = __builtin_nontemporal_load(rgb + 3 * i + 2);
+    const unsigned w[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+    unsigned o[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const int k = 3 * p;
+        const unsigned c0 = (w[k >> 2] >> (8 * (k & 3))) & 255u;
+        const unsigned c1 = (w[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 255u;
+        const unsigned c2 = (w[(k + 2) >> 2] >> (8 * ((k + 2) & 3))) & 255u;
+        o[p >> 2] |= luma8(bgr ? c2 : c0, c1, bgr ? c0 : c2) << (8 * (p & 3));
+    }
+    u32x4 r; r.x = o[0]; r.y = o[1]; r.z = o[2]; r.w = o[3];
+    __builtin_nontemporal_store(r, gray + i);
+}
+// the pixels behind the last whole group of 16 (and unaligned buffers): one pixel per thread
+__global__ void k_rgb2gray(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ gray, size_t first, size_t npix, int bgr) {
+    const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npix) return;
     const uint8_t* p = rgb + 3 * i;
-    const int r = bgr ? p[2] : p[0], g = p[1], b = bgr ? p[0] : p[2];
-    gray[i] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+    gray[i] = (uint8_t)luma8(bgr ? p[2] : p[0], p[1], bgr ? p[0] : p[2]);
 }
 // 2 x 2 box filter, rounded: one pyramid level (u8 row-major H x W -> H/2 x W/2); no reference counterpart
 __global__ void k_downsample_u8(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int H, int W) {
@@ -280,7 +301,11 @@ void launch_downsample_pyr(hipStream_t s, int steps, const uint8_t* a, const uin
     else hipLaunchKernelGGL(k_downsample_pyr<3>, grid, block, 0, s, a, b, na, H, W, out[0], out[1], out[2]);
 }
 void launch_rgb2gray(hipStream_t s, const uint8_t* rgb, uint8_t* gray, size_t npix, int bgr) {
-    hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, rgb, gray, npix, bgr);
+    const bool aligned = (reinterpret_cast<uintptr_t>(rgb) % 16 == 0) && (reinterpret_cast<uintptr_t>(gray) % 16 == 0);
+    const size_t groups = aligned ? npix / 16 : 0, done = groups * 16;
+    if (groups) hipLaunchKernelGGL(k_rgb2gray16, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, reinterpret_cast<const u32x4*>(rgb),
+                                   reinterpret_cast<u32x4*>(gray), groups, bgr);
+    if (done < npix) hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((npix - done + 255) / 256)), dim3(256), 0, s, rgb, gray, done, npix, bgr);
 }
 
 void launch_cvt_u8(hipStream_t s, int n, const uint8_t* arena_u8, size_t u8_stride, int u8_pitch, const int* d_slot, float* arena_img,

@@ -399,6 +399,7 @@ int nik_pg_shard_create(int device, int n_poses, const int32_t* ids, const doubl
     return NIK_OK;
 }
 void nik_pg_shard_destroy(nik_pg_shard* s) { if (s) { kcc_pg::dev_destroy(s->dev); delete s; } }
+int nik_pg_shard_device(const nik_pg_shard* s) { return s ? kcc_pg::dev_device(s->dev) : NIK_ERR_INVALID_ARG; }
 int nik_pg_shard_cost_dev(nik_pg_shard* s, const double* poses, double** d_cost, void** stream) {
     if (!s || !d_cost) return NIK_ERR_INVALID_ARG;
     if (poses) s->x.assign(poses, poses + s->x.size());

@@ -19,5 +19,6 @@ int dev_linearize(DevProblem* p, const double* x, double* cost, double* r, doubl
 // cost only, left ON THE DEVICE: *d_cost points at one double valid after work on *stream (a hipStream_t) has finished
 int dev_cost_async(DevProblem* p, const double* x, double** d_cost, void** stream);
 const char* dev_error(const DevProblem* p);
+int dev_device(const DevProblem* p);                                 // the GPU the problem lives on (-1: null)
 
 }  // namespace kcc_pg

@@ -165,9 +165,13 @@ void dev_destroy(DevProblem* p) {
 }
 
 const char* dev_error(const DevProblem* p) { return p ? p->err.c_str() : ""; }
+int dev_device(const DevProblem* p) { return p ? p->device : -1; }
 
 static int enqueue(DevProblem* p, const double* x, bool normal) {
     PG_TRY(p, hipSetDevice(p->device));
+    // the ONE pinned staging buffer may still be the source of an earlier call's asynchronous upload (dev_cost_async returns
+    // without synchronising): wait for that stream work before the buffer is overwritten
+    PG_TRY(p, hipStreamSynchronize(p->stream));
     std::copy(x, x + 3 * (size_t)p->n_poses, p->h_pin);
     PG_TRY(p, hipMemcpyAsync(p->d_x, p->h_pin, sizeof(double) * 3 * p->n_poses, hipMemcpyHostToDevice, p->stream));
     if (p->n_edges > 0)

@@ -57,6 +57,9 @@ int nik_pyramid_create(const nik_config* cfg, int H, int W, int levels, int max_
         int rc = nik_create(&c, H >> l, W >> l, l == 0 ? max_batch : 2 * max_batch, 2 * max_batch, device, &p->ctx[l]);
         if (!rc) rc = nik_set_call_depth(p->ctx[l], 4);            // spectra + pose per batch, two batches in flight
         if (!rc) rc = nik_set_streams(p->ctx[l], 1) == 1 ? 0 : NIK_ERR_INVALID_ARG;     // (a 2n-frame call of a coarse level would otherwise split)
+        // chained calls must be cut exactly like the level above (nik_pose_batch_chained): the $NIK_CHUNK tuning knob, which
+        // nik_create reads, would chunk the plain call of the coarsest level and not the chained ones
+        if (!rc) rc = nik_set_chunk(p->ctx[l], 0) >= 0 ? 0 : NIK_ERR_INVALID_ARG;
         if (rc) { nik_pyramid_destroy(p); return rc; }
         if (l > 0) {
             const size_t frame = (size_t)(H >> l) * (W >> l);

@@ -373,7 +373,9 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
         std::vector<int> hist = t->gap_hist;
         int guess = nik_tracker::guess_next_gap(hist);             // frames from the current keyframe to the next one (0: no history)
         // first segment: the frames behind the current keyframe, twice as far as the next keyframe is expected
-        const int depth = std::max(1, guess > 0 ? std::max(4, 2 * guess) : t->spec_depth);
+        // (never below the adaptive depth: it doubles after a batch without an insertion, so the window still grows towards
+        // max_batch when the key frames suddenly come further apart than their history says)
+        const int depth = std::max(1, guess > 0 ? std::max({ 4, 2 * guess, t->spec_depth }) : t->spec_depth);
         { const int m0 = std::min({ n - start, depth, t->max_batch });
           for (int i = 0; i < m0; ++i) { keys[i] = t->key_slot; curs[i] = slot[start + i]; }
           segs.push_back({ -1, start, m0, 0 }); total = m0; }

@@ -26,7 +26,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar", "nik_dbg_response",
            "nik_profile_enable", "nik_profile_read", "nik_set_streams", "nik_set_chunk",
            "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_keyframes",
-           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
+           "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_device", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
            "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
@@ -155,6 +155,7 @@ def load():
         L.nik_pg_shard_create.argtypes = [I, I, P, P, I, P, P]
         L.nik_pg_shard_destroy.argtypes = [P]
         L.nik_pg_shard_destroy.restype = None
+        L.nik_pg_shard_device.argtypes = [P]
         L.nik_pg_shard_cost_dev.argtypes = [P, P, P, P]
         L.nik_group_pose_graph_cost.argtypes = [P, P, P, P]
         L.nik_stitcher_create.argtypes = [P, I, P]

@@ -113,6 +113,22 @@ int main(int argc, char** argv) {
         flow.ComputePose(edited, cur, last_p, cp, p2, true);
         if (flow.stats().imports != before + 1) { printf("FAIL side table: an unknown key spectrum was not imported\n"); ++fails; }
         if (p1[0] != p2[0] || p1[1] != p2[1]) { printf("FAIL pose after import\n"); ++fails; }
+        // an in-place edit of ONE element anywhere in an exported array (here one the old 65-sample fingerprint never looked at)
+        // must be noticed: the array is imported instead of the stale device copy being used (by-value semantics)
+        {
+            ColMajor<std::complex<float>> one = cp;
+            const long n = one.rows() * one.cols(), at = n / 2 + 37;
+            one.data()[at] += std::complex<float>(1e-3f, 0.f);
+            const long b2 = flow.stats().imports;
+            Vec3 p3;
+            flow.ComputePose(last_f, cur, last_p, one, p3, true);
+            if (flow.stats().imports != b2 + 1) { printf("FAIL side table: a single edited element went unnoticed\n"); ++fails; }
+            ColMajor<float> img1 = cur;
+            img1.data()[(long)H * W / 3 + 5] += 0.25f;
+            const long b3 = flow.stats().imports;
+            flow.ComputePose(last_f, img1, last_p, cp, p3, true);
+            if (flow.stats().imports <= b3) { printf("FAIL side table: an edited image went unnoticed\n"); ++fails; }
+        }
         ora_destroy(ora);
     }
     {

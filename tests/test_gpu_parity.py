@@ -362,6 +362,12 @@ def test_rgb_1280x720_parity():
     # BGR order flips the weights
     cf.rgb_to_gray_dev(d_rgb.data_ptr(), 1, d_gray[:1].data_ptr(), bgr=True)
     assert np.array_equal(d_gray[0].cpu().numpy(), luma(k_rgb[0][..., ::-1]))
+    # buffers that are not 16-byte aligned take the one-pixel-per-thread kernel: same integers
+    flat_in = torch.empty(3 * H * W + 64, dtype=torch.uint8, device="cuda"); flat_out = torch.zeros(H * W + 64, dtype=torch.uint8, device="cuda")
+    flat_in[3:3 + 3 * H * W] = d_rgb[1].reshape(-1)
+    torch.cuda.synchronize()
+    cf.rgb_to_gray_dev(flat_in.data_ptr() + 3, 1, flat_out.data_ptr() + 1)
+    assert np.array_equal(flat_out[1:1 + H * W].cpu().numpy().reshape(H, W), luma(k_rgb[1])) and int(flat_out[0]) == 0 and int(flat_out[1 + H * W]) == 0
     cf.rgb_to_gray_dev(d_rgb.data_ptr(), 2 * n, d_gray.data_ptr())
     cf.intermedium_batch_dev(d_gray[:n].data_ptr(), n, list(range(n)))
     res = cf.track_batch_dev(d_gray[n:].data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)

@@ -81,12 +81,16 @@ def test_group_through_rccl_single_rank():
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-def _run_bench(world, gb, dump, tmp_path, workload="pairs"):
+def _run_bench(world, gb, dump, tmp_path, workload="pairs", bare=False):
+    """bare: the literal `python bench.py --gpus N` (bench.py starts its own ranks); else under torch.distributed.run, the
+    form the driver uses when it launches the ranks itself"""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NIK_BENCH_GLOBAL_BATCH=str(gb), NIK_BENCH_DUMP=str(dump), NIK_BENCH_DEVICE="0", NIK_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
     common = ["bench.py", "--gpus", str(world), "--workload", workload, "--steps", "2", "--warmup", "1", "--cpu-sample", "0", "--no-profile", "--no-cached",
-              "--no-live-prof"]
-    if world == 1:
+              "--no-live-prof", "--repeats", "2"]
+    if world == 1 or bare:
         cmd = [sys.executable] + common
     else:
         port = 29600 + (os.getpid() % 1000)
@@ -106,8 +110,9 @@ def test_two_ranks_on_one_device_equal_one_rank(tmp_path):
     rendezvous) gives bit for bit the per-pair results of the unsharded run, and the all-reduced statistics agree"""
     gb = 48
     line1, d1 = _run_bench(1, gb, tmp_path / "w1", tmp_path)
-    line2, d2 = _run_bench(2, gb, tmp_path / "w2", tmp_path)
+    line2, d2 = _run_bench(2, gb, tmp_path / "w2", tmp_path, bare=True)        # `python bench.py --gpus 2`, nothing around it
     assert line2["n_gpus"] == 2 and line1["n_gpus"] == 1
+    assert line2["multi_gpu"]["world"] == 2 and line2["timing"]["regions"] == 2
     whole = d1[0]["results"]
     parts = d2[0]["results"] + d2[1]["results"]
     assert len(whole) == gb == len(parts)
@@ -133,3 +138,15 @@ def test_configs3_hd_two_ranks_equal_one_rank(tmp_path):
     assert mg["world"] == 2 and mg["fallback"] is False and mg["rccl_ranks"] == 0        # (gloo test hook: no RCCL communicator)
     assert 0 < mg["pairs_per_s_per_rank_min"] <= mg["pairs_per_s_per_rank_max"]
     assert line1["multi_gpu"]["world"] == 1
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """`--gpus N` under a launcher that created another world size is an error, not a line with the wrong n_gpus (CPU: the
+    check runs before anything is imported)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "WORLD_SIZE=3" in p.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "pyramid"], cwd=root, env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "single-GPU" in p.stderr

@@ -144,6 +144,15 @@ def test_device_linearisation_and_solve_match_the_host(n, loops, seed):
     ids, guess, cons = make_graph(n, seed, loops)
     ch, gh, dh = N.pose_graph_linearize(ids, guess, cons, device=-1)
     cd, gd, dd = N.pose_graph_linearize(ids, guess, cons, device=0)
+    # the DEVICE linearisation against the independent numpy residual / Jacobian written from the reference's error term
+    # (pose_graph_2d_error_term.h:62-116) -- not only against the product's own host code
+    r = residuals(guess[1:].reshape(-1), ids, guess[0], cons)
+    J = jacobian(guess[1:].reshape(-1), ids, guess[0], cons)
+    assert cd == pytest.approx(0.5 * float(r @ r), rel=1e-12)
+    assert np.allclose(gd[1:].reshape(-1), J.T @ r, rtol=1e-10, atol=1e-11) and np.all(gd[0] == 0)
+    Hn = J.T @ J
+    for k in range(1, n):
+        assert np.allclose(dd[k], Hn[3 * (k - 1):3 * k, 3 * (k - 1):3 * k], rtol=1e-10, atol=1e-11)
     # same double arithmetic; only the order of the sums over a pose's constraints / over the constraints may differ
     assert cd == pytest.approx(ch, rel=1e-13)
     assert np.allclose(gd, gh, rtol=1e-12, atol=1e-13) and np.allclose(dd, dh, rtol=1e-12, atol=1e-13)
