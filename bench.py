@@ -396,6 +396,18 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
         spec_box[:] = trk.speculation()
         trk.close(); flow.close()
         return outs, dt
+    def run_host(nframes, src, ptr=None):
+        """the same sequence from HOST memory (nik_tracker_push_host): windows of `win` frames, the next window uploaded on
+        the context's upload stream while the current one is registered"""
+        flow = N.CorrelationFlow(cfg, H, W, max_batch=win, max_frames=nframes + win + 2, device=local_rank)
+        flow.set_kzz_cache(True)
+        trk = N.Tracker(flow, N.tracker_config())
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        outs = trk.push_host(src[:nframes], ptr=ptr)
+        dt = time.perf_counter() - t1
+        trk.close(); flow.close()
+        return outs, dt
     spec_box = [0, 0, 0]
     run(min(T, 256))                                            # warm-up (module load, first launches)
     best, best_g = None, None
@@ -421,6 +433,23 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
         trk.close(); flow.close()
         same = lambda a, b: all(a[k] == b[k] for k in a if k != "slot")          # (slot numbers depend on the window size)
         parity = all(same(one[i], outs[i]) for i in range(ns))
+    host = None
+    if args.host_frames:
+        # host-inclusive rate (the reference's caller hands over host images: main.cpp:55-65): (a) frames in pinned memory -- a
+        # camera driver's DMA ring -- read by the copy engine directly, (b) frames in pageable memory, staged through the
+        # context's pinned buffers by the calling thread
+        pin = torch.from_numpy(seq).pin_memory()
+        run_host(min(T, 256), seq)
+        bp, bq, same_p, same_q = None, None, True, True
+        for _ in range(max(1, args.steps // 10)):
+            o1, dt1 = run_host(T, pin.numpy(), ptr=pin.data_ptr()); bp = dt1 if bp is None else min(bp, dt1)
+            o2, dt2 = run_host(T, seq); bq = dt2 if bq is None else min(bq, dt2)
+            same = lambda a, b: all(a[k] == b[k] for k in a if k != "slot")         # noqa: E731
+            same_p = same_p and all(same(a, b) for a, b in zip(o1, outs)); same_q = same_q and all(same(a, b) for a, b in zip(o2, outs))
+        host = {"frames_per_s_pinned_source": round(T / bp, 1), "frames_per_s_pageable_source": round(T / bq, 1),
+                "frames_per_s_resident": round(T / best_off, 1), "identical_outputs": bool(same_p and same_q),
+                "upload_GBps_pinned": round(T / bp * H * W / 1e9, 2),
+                "note": "nik_tracker_push_host: uploads on the context's own stream (never a compute lane), window k+1 travels while window k is registered; pageable sources are copied into pinned staging by the calling thread"}
     nkey = int(sum(o["inserted"] for o in outs))
     bpf = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
     return _line("frames/s through the tracker (configs[1] as a sequence)", "frames/s", T / best, 1, args, 1e3 * best,
@@ -430,6 +459,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
                  parity_spot_check=parity, roofline=None, cpu_baseline=None,
                  hipgraph={"frames_per_s_off": round(T / best_off, 1), "frames_per_s_on": round(T / best_g, 1),
                            "identical_outputs": bool(graphs_same), "reported": "on" if use_g else "off"},
+                 host_inclusive=host,
                  note="a keyframe switch is a dependent round trip of a small batch unless the tracker guessed the new keyframe from the history of gaps and registered the frames behind it in the same batch (nik_tracker_guess_gap); all outputs equal one-frame-at-a-time pushes")
 
 
@@ -537,6 +567,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2048, help="sequence workload: frames")
     ap.add_argument("--seq-rot-rate", type=float, default=0.25, help="sequence workload, smooth path: degrees per frame")
     ap.add_argument("--seq-motion", default="sawtooth", choices=["sawtooth", "smooth"], help="sequence workload: synthetic camera path")
+    ap.add_argument("--host-frames", action="store_true", help="sequence workload: also run the sequence from HOST memory (pinned and pageable) through nik_tracker_push_host")
     ap.add_argument("--candidates", type=int, default=4096, help="loop4096 workload: resident key frames")
     ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps each (0 = as many as fill --min-time, 3..64); the line reports the median")
     ap.add_argument("--min-time", type=float, default=1.0, help="seconds of timed regions to accumulate when --repeats is 0")

@@ -121,6 +121,22 @@ int nik_intermedium_u8(nik_ctx* ctx, const uint8_t* gray, int stride, nik_frame 
 /* replaces CorrelationFlow::ComputeIntermedium(const ArrayXXf&, ArrayXXcf&, ArrayXXcf&): host f32 image,
  * column-major H x W.  Results stay on the device in slot `dst`; fetch them with nik_frame_export. */
 int nik_intermedium_f32(nik_ctx* ctx, const float* image_colmajor, nik_frame dst);
+
+/* ---- host frames -> device on the context's own UPLOAD stream (never a compute lane) ---------------------------------
+ * The reference's caller hands over host images (main.cpp:55-65, map_builder.cc:30-33: Dataset::GetImage -> AddNewInput).  A
+ * streamed caller uploads the next window of frames while the current one is registered:
+ *   ticket = nik_upload_u8_async(ctx, n, frames, stride, frame_stride, d_dst)   copies enqueued, returns at once (>= 0)
+ *   nik_upload_fence(ctx, ticket)        every compute lane waits ON THE DEVICE for that upload (call it before the *_dev
+ *                                        entry point that reads d_dst; uploads enqueued later do not delay that work)
+ *   nik_upload_wait(ctx)                 host-side: the source buffers of all uploads so far may be reused
+ * A source in pinned memory (hipHostMalloc / hipHostRegister, e.g. a camera driver's DMA ring) is read by the copy engine
+ * directly; a pageable one is staged through two pinned buffers of the context.  At most four uploads may be un-fenced.
+ * nik_dev_malloc / nik_dev_free: device buffers on the context's GPU for callers that do not link the HIP runtime. */
+int nik_upload_u8_async(nik_ctx* ctx, int n, const uint8_t* gray, int stride, size_t frame_stride, uint8_t* d_dst);
+int nik_upload_fence(nik_ctx* ctx, int ticket);
+int nik_upload_wait(nik_ctx* ctx);
+int nik_dev_malloc(nik_ctx* ctx, size_t bytes, void** out);
+int nik_dev_free(nik_ctx* ctx, void* p);
 /* batched, device-resident inputs: n u8 images [n][H][W] (row-major, tightly packed) already in HBM. */
 int nik_intermedium_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_frame* dst);
 
@@ -217,6 +233,10 @@ void nik_tracker_destroy(nik_tracker* t);
 int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out);
 /* one host frame (cv::Mat CV_8UC1) */
 int  nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out);
+/* n host frames (H rows of `stride` bytes each, `frame_stride` bytes apart): the reference's per-frame loop (main.cpp:51-86,
+ * map_builder.cc:30-33) for a streamed caller.  Windows of max_batch frames; window k+1 is uploaded on the context's upload
+ * stream while window k is registered.  Outputs are exactly those of n nik_tracker_push_u8 calls. */
+int  nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride, size_t frame_stride, nik_track_output* out);
 /* number of keyframes inserted so far and their slots (for loop closure: nik_match over these) */
 int  nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n);
 

@@ -115,6 +115,10 @@ struct nik_ctx {
     size_t s_elems = 0, spec_max = 0, r_elems = 0; int partial_stride = 0;
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
+    // host frames -> device on the context's own upload stream (nik_upload_u8_async): never on a compute lane
+    hipStream_t up_stream = nullptr; hipEvent_t up_ev[4] = { nullptr, nullptr, nullptr, nullptr }; unsigned up_seq = 0;
+    uint8_t* up_pin[2] = { nullptr, nullptr }; hipEvent_t up_pin_ev[2] = { nullptr, nullptr }; bool up_pin_busy[2] = { false, false };
+    size_t up_pin_bytes = 0; int up_pin_next = 0;
     float* d_scratch = nullptr;          // debug / import-export staging
     // residual statistics of the latest batch (nik_set_residual_stats): per-lane partials [4 lanes][4] + their sum [4], device
     // They are summed (and all-reduced, nik_group) on their own stream so that no lane waits for another.
@@ -762,6 +766,10 @@ void nik_destroy(nik_ctx* c) {
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->stats_stream) { (void)hipStreamSynchronize(c->stats_stream); (void)hipStreamDestroy(c->stats_stream); }
     if (c->stats_done) (void)hipEventDestroy(c->stats_done);
+    if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
+    for (hipEvent_t e : c->up_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->up_pin_ev) if (e) (void)hipEventDestroy(e);
+    for (uint8_t* q : c->up_pin) if (q) (void)hipHostFree(q);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(const_cast<uint32_t*>(c->polar.chunks)); (void)hipFree(const_cast<int*>(c->polar.seg_first));
     (void)hipFree(const_cast<uint4*>(c->polar.pts)); (void)hipFree(c->rot_tab); (void)hipFree(c->rot_one);
     for (hipEvent_t e : c->chain_ev) if (e) (void)hipEventDestroy(e);
@@ -928,6 +936,84 @@ int nik_intermedium_u8(nik_ctx* c, const uint8_t* gray, int stride, nik_frame ds
     c->active_lanes = keep;
     if (rc) return rc;
     return drain_all(c);
+}
+
+// ---- host frames -> device, on the upload stream ---------------------------------------------------------------------
+// The reference's caller hands over host images one by one (main.cpp:55-65, map_builder.cc:30-33).  A streamed caller uploads the
+// next window of frames while the current one is registered: the copies run on the context's own stream, a pinned source
+// (hipHostMalloc / hipHostRegister: what a camera driver's DMA ring is) is read by the copy engine directly, a pageable one goes
+// through two pinned staging buffers (the CPU copy of piece k+1 overlaps the DMA of piece k).  Returns a ticket; the compute
+// lanes wait for it on the device once nik_upload_fence(ticket) has been called (NOT before: an upload enqueued behind a
+// fence does not delay the work that fence covers -- that is what lets window k+1 travel while window k computes).
+int nik_upload_u8_async(nik_ctx* c, int n, const uint8_t* gray, int stride, size_t frame_stride, uint8_t* d_dst) {
+    if (!c || !gray || !d_dst || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    if (stride < c->W || frame_stride < (size_t)stride * (size_t)c->H) return fail(c, NIK_ERR_INVALID_ARG, "stride %d / frame stride %zu too small for %d x %d frames", stride, frame_stride, c->H, c->W);
+    if (!c->up_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : c->up_ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (hipEvent_t& e : c->up_pin_ev) HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t fb = (size_t)c->H * c->W;
+    hipPointerAttribute_t at{};
+    const bool pinned = hipPointerGetAttributes(&at, gray) == hipSuccess && at.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                                  // (an unregistered pointer reports an error: not ours)
+    if (pinned) {
+        if (frame_stride == (size_t)stride * (size_t)c->H)   // the frames form one tall image: a single 2-D copy
+            HIP_TRY(c, hipMemcpy2DAsync(d_dst, c->W, gray, stride, c->W, (size_t)c->H * n, hipMemcpyHostToDevice, c->up_stream));
+        else
+            for (int i = 0; i < n; ++i)
+                HIP_TRY(c, hipMemcpy2DAsync(d_dst + (size_t)i * fb, c->W, gray + (size_t)i * frame_stride, stride, c->W, c->H, hipMemcpyHostToDevice, c->up_stream));
+    } else {
+        const int per = 8;                                    // frames per staging piece
+        if (c->up_pin_bytes < fb * per) {
+            for (int k = 0; k < 2; ++k) { if (c->up_pin_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->up_pin_ev[k])); c->up_pin_busy[k] = false; } if (c->up_pin[k]) (void)hipHostFree(c->up_pin[k]); c->up_pin[k] = nullptr; }
+            for (int k = 0; k < 2; ++k) HIP_TRY(c, hipHostMalloc(&c->up_pin[k], fb * per));
+            c->up_pin_bytes = fb * per;
+        }
+        for (int b = 0; b < n; b += per) {
+            const int m = std::min(per, n - b), k = c->up_pin_next; c->up_pin_next ^= 1;
+            if (c->up_pin_busy[k]) { HIP_TRY(c, hipEventSynchronize(c->up_pin_ev[k])); c->up_pin_busy[k] = false; }
+            for (int i = 0; i < m; ++i) {
+                const uint8_t* src = gray + (size_t)(b + i) * frame_stride;
+                uint8_t* dst = c->up_pin[k] + (size_t)i * fb;
+                if (stride == c->W) memcpy(dst, src, fb);
+                else for (int r = 0; r < c->H; ++r) memcpy(dst + (size_t)r * c->W, src + (size_t)r * stride, c->W);
+            }
+            HIP_TRY(c, hipMemcpyAsync(d_dst + (size_t)b * fb, c->up_pin[k], fb * m, hipMemcpyHostToDevice, c->up_stream));
+            HIP_TRY(c, hipEventRecord(c->up_pin_ev[k], c->up_stream));
+            c->up_pin_busy[k] = true;
+        }
+    }
+    const unsigned t = c->up_seq++;
+    HIP_TRY(c, hipEventRecord(c->up_ev[t & 3], c->up_stream));
+    return (int)(t & 0x3FFFFFFF);
+}
+// every compute lane waits (on the device) for the upload with this ticket; at most four uploads may be outstanding
+int nik_upload_fence(nik_ctx* c, int ticket) {
+    if (!c || ticket < 0 || !c->up_stream) return fail(c, NIK_ERR_INVALID_ARG, "no such upload");
+    if ((unsigned)ticket + 4 < (c->up_seq & 0x3FFFFFFFu) ) return fail(c, NIK_ERR_INVALID_ARG, "upload ticket %d is older than the four tracked uploads", ticket);
+    int rc = ensure_lanes(c, c->active_lanes);
+    if (rc) return rc;
+    for (int li = 0; li < c->active_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->up_ev[ticket & 3], 0));
+    return NIK_OK;
+}
+// device memory on the context's GPU for callers that do not link the HIP runtime themselves (the host-side tracker's upload ring)
+int nik_dev_malloc(nik_ctx* c, size_t bytes, void** out) {
+    if (!c || !out) return fail(c, NIK_ERR_INVALID_ARG, "null argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMalloc(out, bytes ? bytes : 1));
+    return NIK_OK;
+}
+int nik_dev_free(nik_ctx* c, void* p) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    if (p) { HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipFree(p)); }
+    return NIK_OK;
+}
+// host-side wait: the SOURCE buffers of every upload enqueued so far may be reused
+int nik_upload_wait(nik_ctx* c) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    if (c->up_stream) HIP_TRY(c, hipStreamSynchronize(c->up_stream));
+    return NIK_OK;
 }
 
 int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {

@@ -78,6 +78,7 @@ struct nik_tracker {
     // (optimise when >= 2 have accumulated) and clears them (map_builder.cc:66-67,108-116)
     std::vector<nik_loop_result> loops;
     std::vector<nik_loop_result> all_loops;  // every loop ever found (diagnostics: nik_tracker_loops)
+    uint8_t* d_up[2] = { nullptr, nullptr }; // upload ring of nik_tracker_push_host: two windows of max_batch frames on the device
     // Map::_edges (KCC edges between consecutive keyframes, loop edges) and the keyframes' robot poses
     struct EdgeRec { int from, to, type; double T[3]; };     // type 0 = KCC, 1 = Loop; T in camera units (edge->_T)
     std::vector<EdgeRec> edges;
@@ -268,7 +269,11 @@ int nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker*
     return NIK_OK;
 }
 
-void nik_tracker_destroy(nik_tracker* t) { delete t; }
+void nik_tracker_destroy(nik_tracker* t) {
+    if (!t) return;
+    for (uint8_t* p : t->d_up) if (p) (void)nik_dev_free(t->ctx, p);
+    delete t;
+}
 
 int nik_tracker_attach_map(nik_tracker* t, nik_map* m, int to_find_loop) {
     if (!t) return NIK_ERR_INVALID_ARG;
@@ -444,6 +449,33 @@ int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_tra
     if ((rc = nik_pose(t->ctx, t->key_slot, s, 1, nullptr, nullptr, &r))) { t->free_slots.push_back(s); return rc; }
     if (!apply_result(t, r, s, *out)) t->free_slots.push_back(s);
     return t->map_rc;
+}
+
+// n host frames (cv::Mat CV_8UC1 each: H rows of `stride` bytes, `frame_stride` bytes apart) -- the reference's per-frame loop
+// (main.cpp:51-86: GetImage -> AddNewInput) for a streamed caller.  The frames travel in windows of max_batch: window k+1 is
+// uploaded on the context's upload stream (nik_upload_u8_async: pinned sources by DMA, pageable ones through pinned staging)
+// while window k is registered, so the PCIe transfer hides behind the registration; outputs are those of n push_u8 calls.
+int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride, size_t frame_stride, nik_track_output* out) {
+    if (!t || !gray || !out || n < 0) return NIK_ERR_INVALID_ARG;
+    if (n == 0) return NIK_OK;
+    const size_t fb = (size_t)t->H * t->W;
+    const int win = t->max_batch;
+    int rc;
+    for (uint8_t*& p : t->d_up)
+        if (!p) { void* q = nullptr; if ((rc = nik_dev_malloc(t->ctx, fb * win, &q))) return rc; p = (uint8_t*)q; }
+    int tk = nik_upload_u8_async(t->ctx, std::min(win, n), gray, stride, frame_stride, t->d_up[0]);
+    if (tk < 0) return tk;
+    for (int b = 0, j = 0; b < n; b += win, ++j) {
+        const int m = std::min(win, n - b);
+        if ((rc = nik_upload_fence(t->ctx, tk))) return rc;   // this window's registration waits for ITS upload only
+        if (b + m < n) {
+            // (the other buffer's previous window was consumed by a push_dev that has returned: free to overwrite)
+            tk = nik_upload_u8_async(t->ctx, std::min(win, n - b - m), gray + (size_t)(b + m) * frame_stride, stride, frame_stride, t->d_up[(j + 1) & 1]);
+            if (tk < 0) return tk;
+        }
+        if ((rc = nik_tracker_push_dev(t, m, t->d_up[j & 1], out + b))) return rc;
+    }
+    return nik_upload_wait(t->ctx);
 }
 
 }  // extern "C"

@@ -306,3 +306,54 @@ def test_fused_remove_zero_component_is_bit_identical(geom, monkeypatch):
     _, rp = orc.intermedium(orc.normalize_u8(frames[0]))
     p = got["1"][0][2]
     assert np.abs(p - rp).max() / np.abs(rp).max() < 2e-5
+
+
+def test_smooth_content_translation_near_ties():
+    """Smooth frames (box-filtered over 9 px) have broad correlation peaks: where the GPU's TRANSLATION arg-max is not the
+    oracle's, it must be a one-pixel neighbour whose value ON THE ORACLE'S OWN SURFACE is within the float32 noise of that
+    surface of the oracle's maximum -- a tie the reference's own FFTW build would break by its rounding too.  TRANS_TIE_REL is
+    the measured noise sum of the two float32 implementations against float64 (6.6e-3 + 6.0e-3 of the peak,
+    test_response_noise_bounds_the_tie_tolerance).  Every other difference is a failure.  (round 3 checked this in
+    tools/parity_sweep.py only: profiles/r03e_parity_sweep_blur9.json, 6 such pairs of 1024.)"""
+    from scipy.ndimage import uniform_filter
+    TRANS_TIE_REL = 1.3e-2
+    n, B = 256, 128
+    cf, ora, ocfg = _mk(max_batch=B, max_frames=2 * B)
+    near, exact, ties, gaps = 0, 0, 0, []
+    for b0 in range(0, n, B):
+        keys, curs, motions = synth.make_batch(B, H, W, seed0=50000 + b0, max_shift=48, max_theta=10.0)
+        blur = lambda f: uniform_filter(f.astype(np.float32), 9, mode="wrap").round().astype(np.uint8)      # noqa: E731
+        keys, curs = np.stack([blur(f) for f in keys]), np.stack([blur(f) for f in curs])
+        import torch
+        dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
+        torch.cuda.synchronize()
+        cf.intermedium_batch_dev(dk.data_ptr(), B, list(range(B)))
+        res = cf.track_batch_dev(dc.data_ptr(), list(range(B)), list(range(B, 2 * B)), True, sync=True)
+        poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True, nthreads=min(32, os.cpu_count() or 1))
+        for i in range(B):
+            g = res[i].as_dict()
+
+            def rerun(row, col, i=i):
+                kf, kp = ora.intermedium(ora.normalize_u8(keys[i]))
+                ci = ora.normalize_u8(curs[i]); _, cp = ora.intermedium(ci)
+                ora.force_rotation(row, col)
+                r = ora.compute_pose(kf, ci, kp, cp, True)
+                ora.force_rotation(-1, -1)
+                return r
+            ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], PD, rerun=rerun)
+            if ok:
+                exact += bool(ex); ties += (not ex)
+                continue
+            assert "translation" in msg and "rot argmax" not in msg, "pair %d %s: %s" % (b0 + i, motions[i], msg)
+            cg, co = g["chosen"], dbgs[i]["chosen"]
+            x = ora.normalize_u8(curs[i]); kf, _ = ora.intermedium(ora.normalize_u8(keys[i]))
+            xr = ora.fft(ora.rotate(x, dbgs[i]["degree_used"][co]))
+            _, _, rt, ct, g_o = ora.estimate_trans(kf, xr, 0, want_g=True)
+            gap = float(g_o[ct, rt] - g_o[g["trans_col"][cg], g["trans_row"][cg]]) / float(g_o[ct, rt])
+            d = max(abs(g["trans_row"][cg] - rt), abs(g["trans_col"][cg] - ct))
+            assert d <= 1 and 0 <= gap < TRANS_TIE_REL, "pair %d: GPU arg-max %d px from the oracle's, oracle-surface gap %.3e: %s" % (b0 + i, d, gap, msg)
+            near += 1; gaps.append(round(gap, 7))
+    _out("r04_smooth_content_near_ties.json", dict(pairs=n, blur_px=9, bit_identical=exact, rotation_mirror_ties=ties,
+                                                     translation_near_ties_verified=near, gaps=gaps, tie_rel=TRANS_TIE_REL))
+    assert exact + ties + near == n
+    cf.close()

@@ -199,3 +199,55 @@ def test_keyframe_chain_speculation_changes_nothing():
     assert calls <= n_key - held + n // window + failed and calls < n_key, (calls, n_key, held, failed)
     assert trk1.speculation()[0] == 0
     trk.close(); trk1.close(); flow.close(); flow1.close()
+
+
+@pytest.mark.gpu
+def test_push_host_equals_push_dev():
+    """nik_tracker_push_host -- host frames in windows, window k+1 uploaded on the context's upload stream while window k is
+    registered -- gives exactly the outputs of push_dev over resident frames and of one push_u8 per frame (the reference's
+    per-frame loop, main.cpp:51-86), from pageable memory, from pinned memory and with a padded row stride"""
+    import ctypes as C
+    import torch
+    N = nik()
+    geom = SMALL
+    H, W = geom["H"], geom["W"]
+    n, window = 70, 16                                              # (not a multiple of the window: a short last one)
+    cv = synth.canvas(77, H, W)
+    frames = np.stack([synth.window(cv, H, W, (i % 20) - 10, 2 * (i % 20) - 20, 0.5 * (i % 5)) for i in range(n)])
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    tc = N.tracker_config(fx=600.0 * W / 640, fy=600.0 * W / 640, cx=W / 2 - 3.5, cy=H / 2 + 2.25, height=0.1,
+                          max_distance=0.1, max_angle=0.02, lower_response_thr=8.0, upper_response_thr=9.0)
+    keys = ("frame_id", "inserted", "good_tracking", "key_frame_id", "response", "cf_pose", "robot_pose", "distance")
+
+    def fresh(mb):
+        flow = N.CorrelationFlow(cfg, H, W, max_batch=mb, max_frames=n + window + 2)
+        return flow, N.Tracker(flow, tc)
+    d = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+    flow, trk = fresh(window)
+    want = []
+    for b in range(0, n, window):
+        want += trk.push_dev(d[b:b + window].data_ptr(), min(window, n - b))
+    trk.close(); flow.close()
+    assert sum(o["inserted"] for o in want) >= 4
+    flow, trk = fresh(window)
+    got_pageable = trk.push_host(frames)
+    trk.close(); flow.close()
+    pin = torch.from_numpy(frames).pin_memory()
+    flow, trk = fresh(window)
+    got_pinned = trk.push_host(frames, ptr=pin.data_ptr())
+    trk.close(); flow.close()
+    # padded rows and frames (a cv::Mat ROI): through the C entry point directly
+    pad = np.zeros((n, H + 3, W + 24), np.uint8); pad[:, :H, :W] = frames
+    flow, trk = fresh(window)
+    out = (N.NikTrackOutput * n)()
+    rc = trk._L.nik_tracker_push_host(trk._t, n, pad.ctypes.data_as(C.c_void_p), W + 24, (H + 3) * (W + 24), C.cast(out, C.c_void_p))
+    assert rc == 0
+    got_padded = [o.as_dict() for o in out]
+    trk.close(); flow.close()
+    flow, trk = fresh(1)
+    got_single = [trk.push_u8(f) for f in frames[:24]]
+    trk.close(); flow.close()
+    for name, got in (("pageable", got_pageable), ("pinned", got_pinned), ("padded", got_padded), ("push_u8", got_single)):
+        for a, b in zip(got, want):
+            for k in keys:
+                assert a[k] == b[k], (name, a["frame_id"], k, a[k], b[k])

@@ -290,6 +290,50 @@ __global__ __launch_bounds__(NT, PROBE_WPS) void k_fused(const Params* __restric
     else role_loop<4>(p, f, xcc, lds, &s_ticket);
 }
 
+// ---- fused, generic workgroups: any workgroup runs any phase ------------------------------------------------------------
+// One ordered ticket list per XCD: tiles of (local item i, phase p) are issued in slot D*i + G*(p-1), the groups of a slot
+// interleaved tile by tile.  A ticket only ever waits for tickets issued EARLIER in the same list (deadlock-free), and
+// (D, G) sets how many items are in flight: (1, 1) four, (2, 1) two, (4, 1) one.
+struct Generic {
+    const unsigned* list; int list_len[8]; int list_off[8];
+    unsigned* head; unsigned* done; unsigned* census;
+};
+__global__ __launch_bounds__(NT, PROBE_WPS) void k_generic(const Params* __restrict__ pp, Generic f) {
+    extern __shared__ float lds[];
+    __shared__ unsigned s_ticket;
+    const Params& p = *pp;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    if (threadIdx.x == 0) atomicAdd(f.census + xcc, 1u);
+    const unsigned* list = f.list + f.list_off[xcc];
+    const int len = f.list_len[xcc];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_ticket = atomicAdd(f.head + xcc * 4, 1u);
+        __syncthreads();
+        const unsigned t = s_ticket;
+        if (t >= (unsigned)len) break;
+        const unsigned w = list[t];
+        const int tile = w & 127, ph = ((w >> 7) & 3) + 1, item = __builtin_amdgcn_readfirstlane((int)(w >> 9));
+        if (ph > 1) {
+            if (threadIdx.x == 0) wait_ge(f.done + item * 4 + (ph - 2), ph == 2 ? T1 : ph == 3 ? T2 : T3, p.err, f.census + 8 + xcc);
+            __syncthreads();
+        }
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        if (ph == 1) phase1(p, item, tile, lds, tid);
+        else if (ph == 2) phaseA<2>(p, item, tile, lds, tid);
+        else if (ph == 3) phase3(p, item, tile, lds, tid);
+        else phaseA<4>(p, item, tile, lds, tid);
+        if (ph < 4) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(f.done + item * 4 + (ph - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 static int arg_i(int argc, char** argv, const char* name, int def) {
     for (int i = 1; i + 1 < argc; ++i) if (!strcmp(argv[i], name)) return atoi(argv[i + 1]);
     return def;
@@ -299,7 +343,7 @@ int main(int argc, char** argv) {
     const int n = arg_i(argc, argv, "--items", 256), reps = arg_i(argc, argv, "--reps", 10);
     const int W = arg_i(argc, argv, "--window", 2), wpc = arg_i(argc, argv, "--wpc", 5);
     const int r1 = arg_i(argc, argv, "--r1", 5), r2 = arg_i(argc, argv, "--r2", 5), r3 = arg_i(argc, argv, "--r3", 4), r4 = arg_i(argc, argv, "--r4", 2);
-    const int bypass = arg_i(argc, argv, "--bypass", 1), mode = arg_i(argc, argv, "--mode", 3);      // mode bit 0: separate, bit 1: fused
+    const int bypass = arg_i(argc, argv, "--bypass", 1), mode = arg_i(argc, argv, "--mode", 3);      // mode bit 0: separate, bit 1: fused (phase-specialised roles), bit 2: fused (generic workgroups)
     Params p{};
     // defaults: the VALU instructions per complex element of the real kernels (VALU-alone time x 1024 SIMDs / 1.31 ns)
     p.f1 = arg_i(argc, argv, "--f1", 60); p.f2 = arg_i(argc, argv, "--f2", 128); p.f3 = arg_i(argc, argv, "--f3", 87); p.f4 = arg_i(argc, argv, "--f4", 79);
@@ -318,9 +362,27 @@ int main(int argc, char** argv) {
       if (r1 + r2 + r3 + r4 == 16) {
           int k = 0; while (k < 16) for (int r = 0; r < 4 && k < 16; ++r) if (cnt[r] > 0) { f.pattern[k++] = (unsigned char)r; --cnt[r]; }
       } else for (int k = 0; k < 16; ++k) f.pattern[k] = (unsigned char)(pat[k] - '0'); }
+    const int D = arg_i(argc, argv, "--D", 1), G = arg_i(argc, argv, "--G", 1);
+    std::vector<unsigned> list; Generic gq{};
+    { const int tiles_of[4] = { T1, T2, T3, T4 };
+      for (int x = 0; x < 8; ++x) {
+        gq.list_off[x] = (int)list.size();
+        std::vector<int> items; for (int i = x; i < n; i += 8) items.push_back(i);
+        const int nslots = items.empty() ? 0 : D * ((int)items.size() - 1) + G * 3 + 1;
+        for (int sl = 0; sl < nslots; ++sl) {
+            std::vector<std::pair<int, int>> groups;         // (item, phase-1) issued in this slot, oldest phase first
+            for (int ph = 3; ph >= 0; --ph) { const int r = sl - G * ph; if (r >= 0 && r % D == 0 && r / D < (int)items.size()) groups.push_back({ items[r / D], ph }); }
+            int mt = 0; for (auto& g : groups) mt = std::max(mt, tiles_of[g.second]);
+            for (int t = 0; t < mt; ++t) for (auto& g : groups) if (t < tiles_of[g.second]) list.push_back(((unsigned)g.first << 9) | ((unsigned)g.second << 7) | (unsigned)t);
+        }
+        gq.list_len[x] = (int)list.size() - gq.list_off[x];
+      } }
+    unsigned* d_list; CK(hipMalloc(&d_list, 4 * list.size() + 4)); CK(hipMemcpy(d_list, list.data(), 4 * list.size(), hipMemcpyHostToDevice));
     unsigned *d_head, *d_done, *d_census;
     CK(hipMalloc(&d_head, 128)); CK(hipMalloc(&d_done, 16 * (size_t)n)); CK(hipMalloc(&d_census, 96));
     f.head = d_head; f.done = d_done; f.census = d_census;
+    gq.list = d_list; gq.head = d_head; gq.done = d_done; gq.census = d_census;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_generic), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
 
     Params* d_params; CK(hipMalloc(&d_params, sizeof(Params)));
@@ -339,6 +401,12 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(d_head, 0, 128, st)); CK(hipMemsetAsync(d_done, 0, 16 * (size_t)n, st)); CK(hipMemsetAsync(d_census, 0, 96, st));
         CK(hipMemcpyAsync(d_params, &p, sizeof(Params), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_fused, dim3(256 * wpc), dim3(NT), LDS_BYTES, st, (const Params*)d_params, f);
+    };
+    auto run_generic = [&]() {
+        p.epoch = epoch++;
+        CK(hipMemsetAsync(d_head, 0, 128, st)); CK(hipMemsetAsync(d_done, 0, 16 * (size_t)n, st)); CK(hipMemsetAsync(d_census, 0, 96, st));
+        CK(hipMemcpyAsync(d_params, &p, sizeof(Params), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_generic, dim3(256 * wpc), dim3(NT), LDS_BYTES, st, (const Params*)d_params, gq);
     };
     auto time_it = [&](auto&& fn, const char* name) {
         fn(); fn(); CK(hipStreamSynchronize(st));
@@ -363,5 +431,14 @@ int main(int argc, char** argv) {
         printf("; dependency polls %llu\n", polls);
     }
     if ((mode & 3) == 3) printf("fused / separate = %.3f\n", b / a);
+    if (mode & 4) {
+        const float c = time_it(run_generic, "generic");
+        unsigned cz[24]; CK(hipMemcpy(cz, d_census, 96, hipMemcpyDeviceToHost));
+        unsigned long long polls = 0; for (int x = 0; x < 8; ++x) polls += cz[8 + x];
+        printf("generic: lag D=%d G=%d (%s items in flight per XCD), %d workgroups per CU; workgroups per XCD", D, G, D == 1 ? "4" : D == 2 ? "2" : "1-2", wpc);
+        for (int x = 0; x < 8; ++x) printf(" %u", cz[x]);
+        printf("; dependency polls %llu over %zu tickets\n", polls, list.size());
+        if (mode & 1) printf("generic / separate = %.3f\n", c / a);
+    }
     return 0;
 }

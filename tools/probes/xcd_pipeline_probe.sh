@@ -18,12 +18,21 @@ echo "== no arithmetic, window 1"; timeout 120 $BIN --items 256 --f1 0 --f2 0 --
 echo "== half arithmetic"; timeout 120 $BIN --items 256 --f1 30 --f2 64 --f3 43 --f4 40
 echo "== plain consumer loads (no L1 bypass): the tag check must catch stale words if the protocol needs the bypass"; timeout 120 $BIN --items 256 --bypass 0 --mode 2
 echo "== 64 items (intermediates fit the Infinity Cache)"; timeout 120 $BIN --items 64 --reps 40
+for dg in "1 1" "2 1" "4 1" "1 2" "2 2" "3 1"; do set -- $dg; echo "== generic workgroups, lag D=$1 G=$2"; timeout 120 $BIN --items 256 --mode 5 --D $1 --G $2; done
+echo "== generic, D=1 G=1, 4 workgroups per CU"; timeout 120 $BIN --items 256 --mode 4 --wpc 4
+echo "== generic, D=1 G=1, no arithmetic"; timeout 120 $BIN --items 256 --mode 5 --f1 0 --f2 0 --f3 0 --f4 0
+echo "== generic, D=2 G=1, no arithmetic"; timeout 120 $BIN --items 256 --mode 5 --D 2 --f1 0 --f2 0 --f3 0 --f4 0
+echo "== generic, D=1 G=1, plain consumer loads"; timeout 120 $BIN --items 256 --mode 4 --bypass 0
 } > $OUT/runs.txt 2>&1
+rm -f $OUT/pmc.txt
 # fabric traffic: separate rocprofv3 passes per counter (never combined with other traces)
 for c in FETCH_SIZE WRITE_SIZE; do
-  for m in 1 2; do
-    rm -rf /tmp/xp_$c_$m
-    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/xp_${c}_$m -- $OLDPWD/$BIN --items 256 --reps 4 --mode $m > /dev/null 2>&1)
+  for m in 1 2 4 42; do
+    rm -rf /tmp/xp_${c}_$m
+    extra=""; mm=$m
+    if [ $m = 2 ]; then extra="--window 8"; fi
+    if [ $m = 42 ]; then extra="--D 2"; mm=4; fi
+    (cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/xp_${c}_$m -- $OLDPWD/$BIN --items 256 --reps 4 --mode $mm $extra > /dev/null 2>&1)
     python3 - "$c" "$m" /tmp/xp_${c}_$m >> $OUT/pmc.txt <<'PY'
 import csv, glob, sys, collections
 c, m, d = sys.argv[1:4]
