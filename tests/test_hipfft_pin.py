@@ -30,37 +30,41 @@ def _hipfft():
     L.hipfftExecR2C.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipfftExecC2R.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.hipfftDestroy.argtypes = [C.c_void_p]
+    # device buffers through the HIP runtime hipFFT itself links (no torch in this test: two HIP runtimes in one process --
+    # torch bundles its own -- did not both find the GPU once hipFFT was loaded)
+    R = C.CDLL("libamdhip64.so")
+    R.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    R.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    R.hipFree.argtypes = [C.c_void_p]
+    L.rt = R
     return L
+
+
+def _run(L, kind, src, out_shape, out_dtype, cols, rows):
+    R = L.rt
+    src = np.ascontiguousarray(src)
+    out = np.empty(out_shape, out_dtype)
+    d_in, d_out, plan = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert R.hipMalloc(C.byref(d_in), src.nbytes) == 0 and R.hipMalloc(C.byref(d_out), out.nbytes) == 0
+    assert R.hipMemcpy(d_in, src.ctypes.data_as(C.c_void_p), src.nbytes, 1) == 0
+    assert L.hipfftPlan2d(C.byref(plan), cols, rows, kind) == 0
+    assert (L.hipfftExecR2C if kind == HIPFFT_R2C else L.hipfftExecC2R)(plan, d_in, d_out) == 0
+    assert R.hipDeviceSynchronize() == 0
+    assert R.hipMemcpy(out.ctypes.data_as(C.c_void_p), d_out, out.nbytes, 2) == 0
+    L.hipfftDestroy(plan); R.hipFree(d_in); R.hipFree(d_out)
+    return out
 
 
 def _hipfft_r2c(L, x):
     """x: numpy (cols, rows) float32 = the column-major rows x cols array handed to FFTW as row-major cols x rows"""
-    import torch
     cols, rows = x.shape
-    d_in = torch.from_numpy(np.ascontiguousarray(x)).cuda()
-    d_out = torch.empty((cols, rows // 2 + 1), dtype=torch.complex64, device="cuda")
-    torch.cuda.synchronize()
-    plan = C.c_void_p()
-    assert L.hipfftPlan2d(C.byref(plan), cols, rows, HIPFFT_R2C) == 0
-    assert L.hipfftExecR2C(plan, d_in.data_ptr(), d_out.data_ptr()) == 0
-    torch.cuda.synchronize()
-    L.hipfftDestroy(plan)
-    return d_out.cpu().numpy()
+    return _run(L, HIPFFT_R2C, x.astype(np.float32), (cols, rows // 2 + 1), np.complex64, cols, rows)
 
 
 def _hipfft_c2r(L, xf):
-    import torch
     cols, hr = xf.shape
-    rows = (hr - 1) * 2
-    d_in = torch.from_numpy(np.ascontiguousarray(xf)).cuda()               # (c2r may destroy its input: a private copy)
-    d_out = torch.empty((cols, rows), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
-    plan = C.c_void_p()
-    assert L.hipfftPlan2d(C.byref(plan), cols, rows, HIPFFT_C2R) == 0
-    assert L.hipfftExecC2R(plan, d_in.data_ptr(), d_out.data_ptr()) == 0
-    torch.cuda.synchronize()
-    L.hipfftDestroy(plan)
-    return d_out.cpu().numpy() / np.float32(rows * cols)                     # IFFT: x / x.size() (correlation_flow.cc:76)
+    rows = (hr - 1) * 2                                                      # (c2r may destroy its input: _run uploads a private copy)
+    return _run(L, HIPFFT_C2R, xf.astype(np.complex64), (cols, rows), np.float32, cols, rows) / np.float32(rows * cols)   # IFFT: x / x.size() (correlation_flow.cc:76)
 
 
 def _relmax(a, b):

@@ -47,7 +47,7 @@ constexpr int T2 = T2Z + T2X;
 constexpr int T3 = (NK + LK3 - 1) / LK3;          // 61 tiles (the library: 8 rows, 46 tiles; 6 keeps every role under 96 VGPRs)
 constexpr int T4 = NL / LXA;                      // 40 tiles
 constexpr int NT = 256;
-constexpr int LDS_BYTES = 32 * 1024;              // what the real kernels hold per workgroup (4-5 workgroups per CU)
+static int LDS_BYTES = 32 * 1024;                 // what the real kernels hold per workgroup (4-5 workgroups per CU); --lds overrides (occupancy study)
 
 struct Params {
     const float2* X; const float2* Z;             // [items][PLANE] inputs (streamed once)
@@ -344,6 +344,7 @@ int main(int argc, char** argv) {
     const int W = arg_i(argc, argv, "--window", 2), wpc = arg_i(argc, argv, "--wpc", 5);
     const int r1 = arg_i(argc, argv, "--r1", 5), r2 = arg_i(argc, argv, "--r2", 5), r3 = arg_i(argc, argv, "--r3", 4), r4 = arg_i(argc, argv, "--r4", 2);
     const int bypass = arg_i(argc, argv, "--bypass", 1), mode = arg_i(argc, argv, "--mode", 3);      // mode bit 0: separate, bit 1: fused (phase-specialised roles), bit 2: fused (generic workgroups)
+    LDS_BYTES = arg_i(argc, argv, "--lds", LDS_BYTES);
     Params p{};
     // defaults: the VALU instructions per complex element of the real kernels (VALU-alone time x 1024 SIMDs / 1.31 ns)
     p.f1 = arg_i(argc, argv, "--f1", 60); p.f2 = arg_i(argc, argv, "--f2", 128); p.f3 = arg_i(argc, argv, "--f3", 87); p.f4 = arg_i(argc, argv, "--f4", 79);
