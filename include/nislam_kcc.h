@@ -80,6 +80,10 @@ void nik_destroy(nik_ctx* ctx);
 const char* nik_last_error(const nik_ctx* ctx);      /* ctx may be NULL: last create() error */
 /* geometry queries (H, W, PD, PC, max_batch, max_frames) */
 int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
+/* 1 if the context runs the any-size kernel family (kcc_generic.hip: geometries outside the tiled kernels' instantiated set --
+ * half-rows {30,60,120,224,240,360,600}, lines {80,160,320,448,480,640,1280,1600}, W and PC multiples of 16, aspect within
+ * 2:1 -- or $NIK_GENERIC=1), 0 if it runs the tiled kernels.  Same results either way; the any-size family is slower. */
+int  nik_is_generic(const nik_ctx* ctx);
 /* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
 int   nik_device(const nik_ctx* ctx);                        /* HIP device ordinal the context lives on */

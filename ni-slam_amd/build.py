@@ -10,11 +10,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 # -fno-slp-vectorize: the FFT engine issues its packed FP32 (v_pk_*_f32 with op_sel / neg modifiers) through inline asm
 # (kcc_fft.h); what the SLP vectoriser packs on its own costs more in register shuffles than it saves (measured +9 %)
-UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_group.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
+UNITS = [("kcc_kernels.hip", ["-fno-slp-vectorize"]), ("kcc_generic.hip", ["-fno-slp-vectorize"]), ("kcc_api.hip", ["-ffp-contract=off"]), ("kcc_tables.cpp", ["-ffp-contract=off"]), ("kcc_group.cpp", ["-ffp-contract=off"]), ("kcc_tracker.cpp", ["-ffp-contract=off"]),
          ("kcc_camera.cpp", ["-ffp-contract=off"]), ("kcc_map.cpp", ["-ffp-contract=off"]),
          ("kcc_posegraph.cpp", ["-ffp-contract=off"]), ("kcc_posegraph_dev.hip", ["-ffp-contract=off"]), ("kcc_pyramid.cpp", ["-ffp-contract=off"]),
          ("kcc_stitcher.hip", ["-ffp-contract=off"])]
-HEADERS = ["kcc_posegraph_dev.h", "kcc_tables.h", "kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
+HEADERS = ["kcc_posegraph_dev.h", "kcc_tables.h", "kcc_fft.h", "kcc_fft2.h", "kcc_consts.h", "kcc_kernels.h", "kcc_generic.h", "kcc_pointwise.h", os.path.join("..", "..", "include", "nislam_kcc.h")]
 
 
 def _stale(target, deps):

@@ -9,6 +9,7 @@
 // while the previous one is still running; results are finalised lazily (nik_synchronize or ring reuse).
 #include "../../include/nislam_kcc.h"
 #include "kcc_kernels.h"
+#include "kcc_generic.h"
 #include "kcc_tables.h"
 
 #include <algorithm>
@@ -68,6 +69,7 @@ struct Lane {
     float2* gbuf = nullptr;             // [cap_items][max spec]
     float*  splane = nullptr;           // [cap_pairs][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
     uint8_t* u8tmp = nullptr;           // [cap_pairs][H*W] undistorted frames (allocated by nik_set_undistort)
+    float*  rbuf = nullptr;             // generic-size contexts: [cap_items][2][max real plane] real work planes
     Partial* partials = nullptr;
     unsigned* maxbuf = nullptr; float* energy = nullptr;
     std::vector<int> idx_shadow; int idx_shadow_n[5] = { 0, 0, 0, 0, 0 }; bool idx_force = false;   // host mirror of d_idx[0, IX_ROTIDX) and the valid prefix of each array
@@ -91,6 +93,8 @@ struct nik_ctx {
     std::string err;
 
     Family img, pol;
+    // any-size fallback (kcc_generic.hip): set when the geometry is outside the tiled kernels' instantiated set (or $NIK_GENERIC=1)
+    bool generic = false; GFamily gimg{}, gpol{}; float2* g_tw[4] = { nullptr, nullptr, nullptr, nullptr }; uint32_t* g_polar_map = nullptr;
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
     // The image of a frame lives as u8 (row-major, what the u8 entry points receive) or as f32 (column-major, what the
     // reference's ArrayXXf entry points hand over); slot_kind says which copies are valid.
@@ -197,6 +201,7 @@ int upload_table(nik_ctx* c, const std::vector<float2>& h, float2** d) {
 int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     f.g.rows = rows; f.g.cols = cols; f.g.hr = rows / 2 + 1;
     f.real_elems = (size_t)rows * cols; f.spec_elems = (size_t)f.g.hr * cols;
+    if (c->generic) return NIK_OK;                           // (run-time plans: generic_init)
     if (kfwd_parts(f.g, false) > KCC_MAXPARTS) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%d x %d: more running-max parts than KCC_MAXPARTS", rows, cols);
     const int h = rows / 2;
     const PlanDesc ph = plan_desc(h), pc = plan_desc(cols);
@@ -209,6 +214,22 @@ int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     f.t.colsA_f = f.d_tw[7]; f.t.colsA_i = f.d_tw[8];
     f.t.halfI_f = f.d_tw[5]; f.t.halfI_i = f.d_tw[6];
     f.t.half_f = f.d_tw[0]; f.t.half_i = f.d_tw[1]; f.t.tw_full = f.d_tw[2]; f.t.cols_f = f.d_tw[3]; f.t.cols_i = f.d_tw[4];
+    return NIK_OK;
+}
+
+// any-size contexts: run-time FFT plans (one exp(-2 pi i k / n) table per line length, evaluated in double) and the per-pixel
+// polar map (the same build_polar_map the tiled kernel's plan is derived from)
+int generic_init(nik_ctx* c) {
+    const int len[4] = { c->H, c->W, c->PD, c->PC };
+    for (int q = 0; q < 4; ++q) { int rc = upload_table(c, twiddles(len[q], len[q]), &c->g_tw[q]); if (rc) return rc; }
+    c->gimg.g = c->img.g; c->gimg.prow = gplan_make(c->H, c->g_tw[0]); c->gimg.pcol = gplan_make(c->W, c->g_tw[1]);
+    c->gpol.g = c->pol.g; c->gpol.prow = gplan_make(c->PD, c->g_tw[2]); c->gpol.pcol = gplan_make(c->PC, c->g_tw[3]);
+    for (const GPlan* p : { &c->gimg.prow, &c->gimg.pcol, &c->gpol.prow, &c->gpol.pcol })
+        if (p->nr == 0) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "FFT length %d has more prime factors than the run-time plan holds", p->n);
+    std::vector<uint32_t> map; std::string err;
+    if (build_polar_map(c->H, c->W, c->PD, c->PC, map, err)) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
+    HIP_TRY(c, hipMalloc(&c->g_polar_map, sizeof(uint32_t) * map.size()));
+    HIP_TRY(c, hipMemcpy(c->g_polar_map, map.data(), sizeof(uint32_t) * map.size(), hipMemcpyHostToDevice));
     return NIK_OK;
 }
 
@@ -418,7 +439,8 @@ int ensure_f32_images(nik_ctx* c, Lane& L, int li, int n, const nik_frame* slots
     if (!k) return NIK_OK;
     int rc = upload_idx(c, L, IX_CVT, k);
     if (rc) return rc;
-    launch_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
+    if (c->generic) g_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
+    else launch_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
     // published as a slot write of this lane: other lanes order their reads of the new planes after it
     L.write_seq += 1;
     HIP_TRY(c, hipEventRecord(L.write_ev, L.stream));
@@ -472,7 +494,29 @@ inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // 
 // defer_polar_B: leave the polar spectrum's second (radius) pass to the caller -- the pose that follows fuses it into
 // its first kernel (fwd_mul_inv), which also writes the finished spectrum to the frame store.  L.tmpA then holds the
 // half-transformed polar spectra.
+// the same for a context of the any-size family (kcc_generic.hip): every stage its own launch, planes in the lane's buffers
+void enqueue_intermedium_generic(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8) {
+    hipStream_t s = L.stream;
+    const int* dst = didx(L, IX_DST);
+    const Family& I = c->img; const Family& P = c->pol;
+    const size_t RS = 2 * c->r_elems;                        // real work planes per item: [2][r_elems]
+    if (d_u8) {
+        if (c->ud_map1) { launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W); d_u8 = L.u8tmp; }
+        Stage st(c, L, "kg_intermedium", n * (double)(c->img.real_elems));
+        g_u8_load(s, n, d_u8, c->img.real_elems, L.rbuf, RS, c->arena_u8, c->u8_stride, c->u8_pitch, dst, c->H, c->W);
+        g_rfft2(s, n, c->gimg, L.rbuf, RS, c->H, nullptr, c->arena_F, I.spec_elems, dst);
+    } else {
+        g_rfft2(s, n, c->gimg, c->arena_img, c->img_stride, c->img_pitch, dst, c->arena_F, I.spec_elems, dst);
+    }
+    g_abs(s, n, c->arena_F, I.spec_elems, dst, L.gbuf, c->spec_max, I.spec_elems);                // fft_result.abs()           (:92)
+    g_irfft2(s, n, c->gimg, L.gbuf, c->spec_max, nullptr, L.rbuf + c->r_elems, RS, c->H);         // the zero-phase image       (:92)
+    g_shift_fix(s, n, L.rbuf + c->r_elems, RS, L.splane, c->s_elems, c->H, c->W);                 // RemoveZeroComponent, fftshift (:93-94)
+    g_polar(s, n, L.splane, c->s_elems, c->g_polar_map, L.rbuf, RS, c->H, c->PD, c->PC);          // polar                      (:94)
+    g_rfft2(s, n, c->gpol, L.rbuf, RS, c->PD, nullptr, c->arena_P, P.spec_elems, dst);
+}
+
 void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool defer_polar_B = false) {
+    if (c->generic) { enqueue_intermedium_generic(c, L, n, d_u8); return; }
     hipStream_t s = L.stream;
     const int* dst = didx(L, IX_DST);
     const Family& I = c->img; const Family& P = c->pol;
@@ -512,6 +556,22 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     hipStream_t s = L.stream;
     const double xs_bytes = xstore ? n * Cb(f) : 0.0;        // x_fwd with xstore: the forward spectrum is written out too
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
+    if (c->generic) {
+        // any-size family: Kzz and Kxz side by side as 2n planes (x_fwd never set: generic contexts do not defer passes)
+        const GFamily& gf = (&f == &c->pol) ? c->gpol : c->gimg;
+        Stage st(c, L, (&f == &c->pol) ? "kg_estimate_rot" : "kg_estimate_trans", 0.0);
+        if (c->cfg.kernel == 1) launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
+        g_mul(s, n, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, f.spec_elems, L.maxbuf);
+        g_irfft2(s, 2 * n, gf, L.kbuf, plane_stride, nullptr, L.rbuf, c->r_elems, f.g.rows);       // xz = IFFT(xzf)          (:212)
+        g_kernel(s, n, L.rbuf, c->r_elems, f.real_elems, kernel_fn(c), L.energy, L.maxbuf);        // kernel, max            (:213-214)
+        g_rfft2(s, 2 * n, gf, L.rbuf, c->r_elems, f.g.rows, nullptr, L.kbuf, plane_stride, nullptr);   // FFT(kernel)          (:215)
+        g_solve(s, n, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, f.g.cols, f.spec_elems);   // (:171-172)
+        g_irfft2(s, n, gf, L.gbuf, c->spec_max, nullptr, L.rbuf, 2 * c->r_elems, f.g.rows);        // g = IFFT(G)            (:173)
+        g_argmax(s, n, L.rbuf, 2 * c->r_elems, f.g.rows, f.g.cols, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror);
+        launch_finalize(s, n, L.partials, c->partial_stride, g_argmax_blocks(f.g.rows, f.g.cols), out, rot_index, n_hyp, c->PD, L.mirror);
+        L.mirror = nullptr;
+        return;
+    }
     if (c->cfg.kernel == 1 && !x_fwd)
         launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
     const bool cached = c->kzz_cache;
@@ -569,6 +629,16 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
                      c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp, nullptr, 0, nullptr, wrot);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
+    if (c->generic) {
+        // RotateArray + FFT, unfused: the rotated planes, then their spectra in tmpA
+        g_rotate(s, nt, img_u8 ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG),
+                 c->rot_tab, didx(L, IX_ROTIDX), L.rbuf, 2 * c->r_elems, c->H, c->W);
+        g_rfft2(s, nt, c->gimg, L.rbuf, 2 * c->r_elems, c->H, nullptr, L.tmpA, c->spec_max, nullptr);
+        L.mirror = L.cur->h_trans;
+        enqueue_estimate(c, L, nt, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
+                         didx(L, IX_TKEY), L.trans_res, nullptr, 1, nullptr, 0, nullptr, wtr);
+        return NIK_OK;
+    }
     if (img_u8) {
         Stage st(c, L, kname("kA_fwd", c->H / 2, "rot8", a_tag(c, c->img)).c_str(), nt * (1.0 * c->img.real_elems + Cb(c->img)));
         launch_A_fwd_rot8(s, nt, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_TIMG), c->rot_tab,
@@ -638,6 +708,7 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
     // (+16: the polar gather stages whole 16-float chunks, the last of which may start at the plane's last pixel)
     HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
     HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * (c->s_elems * c->max_batch + 16)));      // zero borders are never overwritten
+    if (c->generic) HIP_TRY(c, hipMalloc(&L.rbuf, sizeof(float) * 2 * c->r_elems * c->max_items));
     HIP_TRY(c, hipMalloc(&L.partials, sizeof(Partial) * c->partial_stride * c->max_items));
     HIP_TRY(c, hipMalloc(&L.maxbuf, sizeof(unsigned) * 2 * KCC_MAXPARTS * c->max_items));
     HIP_TRY(c, hipMemset(L.maxbuf, 0, sizeof(unsigned) * 2 * KCC_MAXPARTS * c->max_items));
@@ -657,7 +728,7 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl) {
 }
 void lane_free(Lane& L) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
-    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.partials);
+    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.rbuf); (void)hipFree(L.partials);
     (void)hipFree(L.maxbuf); (void)hipFree(L.energy); (void)hipFree(L.rot_res); (void)hipFree(L.trans_res); (void)hipFree(L.d_idx);
     for (Call& call : L.ring) {
         if (call.h_idx) (void)hipHostFree(call.h_idx);
@@ -691,11 +762,15 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     const int H = image_height, W = image_width, PD = cfg->rotation_divisor, PC = cfg->rotation_channel;
     if ((H & 1) || (W & 1) || (PD & 1) || (PC & 1) || PD <= 0 || PC <= 0)
         return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "height, width, rotation_divisor and rotation_channel must be even");
-    if (!fft_half_supported(H / 2) || !fft_half_supported(PD / 2) || !fft_line_supported(W) || !fft_line_supported(PC))
-        return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "FFT length not instantiated for %dx%d / polar %dx%d", H, W, PD, PC);
-    if (W % 16 || PC % 16) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "width and rotation_channel must be multiples of 16");
-    if (H / 2 + 2 > W || W / 2 + 2 > H)      // keeps every de-rotated source coordinate within one period (single-step BORDER_WRAP)
-        return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "aspect ratio beyond 2:1 is not supported");
+    // The tiled kernels are compile-time plans: half-rows / line lengths of a closed set, 16-column tiles (W, PC multiples of
+    // 16) and an aspect ratio within 2:1 (every de-rotated source coordinate then stays within one period: single-step
+    // BORDER_WRAP).  Every other geometry the reference accepts (correlation_flow.cc:53-77: any size with even rows) runs the
+    // any-size family (kcc_generic.hip): slower, same results.  $NIK_GENERIC=1 forces it (tests compare the two families).
+    const bool tiled = fft_half_supported(H / 2) && fft_half_supported(PD / 2) && fft_line_supported(W) && fft_line_supported(PC) &&
+                       W % 16 == 0 && PC % 16 == 0 && !(H / 2 + 2 > W || W / 2 + 2 > H);
+    const bool generic = !tiled || (getenv("NIK_GENERIC") && atoi(getenv("NIK_GENERIC")) != 0);
+    if (generic && (std::max({ H, W, PD, PC }) > 8192 || H < 4 || W < 4 || PD < 4 || PC < 4))
+        return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "any-size path: lengths from 4 to 8192 (got %dx%d / polar %dx%d)", H, W, PD, PC);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, NIK_ERR_HIP, "no HIP device available (the HIP path has no CPU fallback)");
@@ -704,6 +779,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->cfg = *cfg; c->cfg.height = H; c->cfg.width = W;      // correlation_flow.cc:40-41
     c->H = H; c->W = W; c->PD = PD; c->PC = PC; c->max_batch = max_batch; c->max_frames = max_frames; c->device = device;
     c->max_items = 2 * max_batch;
+    c->generic = generic;
     auto bail = [&](int rc) { g_create_error = c->err; nik_destroy(c); return rc; };
 #define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, NIK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(NIK_ERR_HIP); } } while (0)
     TRY_C(hipSetDevice(device));
@@ -712,7 +788,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->spec_max = std::max(c->img.spec_elems, c->pol.spec_elems);
     c->s_elems = (size_t)(W + 1) * (H + 2);
     c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
-    c->partial_stride = std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
+    c->partial_stride = generic ? std::max(g_argmax_blocks(H, W), g_argmax_blocks(PD, PC)) : std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
+    if (generic && (rc = generic_init(c))) return bail(rc);
     // column pitch: >= H + 4 (wrap rows), a multiple of 32 floats (columns start on 128-byte lines) and an ODD multiple
     // (no power-of-two stride across HBM channels)
     c->img_pitch = ((H + 4 + 31) / 32) * 32;
@@ -749,7 +826,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if ((rc = lane_alloc(c, c->lanes[0], nl))) return bail(rc);
     TRY_C(hipMalloc(&c->d_u8, (size_t)H * W));
     TRY_C(hipMalloc(&c->d_scratch, sizeof(float) * std::max(c->img.real_elems, 2 * c->spec_max) * 2));
-    if ((rc = build_polar_table(c)) || (rc = build_rot_table(c))) return bail(rc);
+    if (generic) { c->fuse_polar = false; c->kzz_cache = false; c->graph_max = 0; }    // (the any-size family has no fused / cached / captured forms)
+    if ((!generic && (rc = build_polar_table(c))) || (rc = build_rot_table(c))) return bail(rc);
     TRY_C(hipDeviceSynchronize());
 #undef TRY_C
     *out = c;
@@ -770,6 +848,8 @@ void nik_destroy(nik_ctx* c) {
     for (hipEvent_t e : c->up_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->up_pin_ev) if (e) (void)hipEventDestroy(e);
     for (uint8_t* q : c->up_pin) if (q) (void)hipHostFree(q);
+    for (float2* q : c->g_tw) (void)hipFree(q);
+    (void)hipFree(c->g_polar_map);
     (void)hipFree(c->d_u8); (void)hipFree(c->d_scratch); (void)hipFree(const_cast<uint32_t*>(c->polar.chunks)); (void)hipFree(const_cast<int*>(c->polar.seg_first));
     (void)hipFree(const_cast<uint4*>(c->polar.pts)); (void)hipFree(c->rot_tab); (void)hipFree(c->rot_one);
     for (hipEvent_t e : c->chain_ev) if (e) (void)hipEventDestroy(e);
@@ -787,6 +867,7 @@ int nik_get_dims(const nik_ctx* c, int dims[6]) {
     return NIK_OK;
 }
 int nik_device(const nik_ctx* c) { return c ? c->device : -1; }
+int nik_is_generic(const nik_ctx* c) { return c ? (c->generic ? 1 : 0) : NIK_ERR_INVALID_ARG; }
 void* nik_stream(const nik_ctx* c) { return c ? (void*)c->lanes[0].stream : nullptr; }
 
 int nik_set_streams(nik_ctx* c, int n) {
@@ -850,7 +931,7 @@ int nik_set_graphs(nik_ctx* c, int max_pairs) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc = drain_all(c);
     if (rc) return rc;
-    c->graph_max = std::max(0, max_pairs);
+    c->graph_max = c->generic ? 0 : std::max(0, max_pairs);
     return NIK_OK;
 }
 
@@ -858,7 +939,7 @@ int nik_set_kzz_cache(nik_ctx* c, int enable) {
     if (!c) return NIK_ERR_INVALID_ARG;
     int rc = drain_all(c);
     if (rc) return rc;
-    c->kzz_cache = enable != 0;
+    c->kzz_cache = enable != 0 && !c->generic;                // (the any-size family recomputes Kzz: same results)
     return NIK_OK;
 }
 
@@ -1024,7 +1105,7 @@ int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {
     if ((rc = begin_call(c, L)) || (rc = depend_for_write(c, L, 0, dst))) return rc;
     HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)dst * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
                                 sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, L.stream));
-    launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);
+    if (!c->generic) launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);   // (the any-size rotate wraps by index)
     hidx(L, IX_DST)[0] = dst;
     if ((rc = upload_idx(c, L, IX_DST, 1))) return rc;
     enqueue_intermedium(c, L, 1, nullptr);
@@ -1067,7 +1148,7 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
     if (image) {
         HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
                                     sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, s));
-        launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
+        if (!c->generic) launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
         c->slot_ready[f] |= 1; c->slot_kind[f] = 2;
     }
     if (fft_result) {
@@ -1612,8 +1693,12 @@ int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     float* d_in = c->d_scratch;                                                   // first half: real input
     float2* d_out = reinterpret_cast<float2*>(c->d_scratch) + c->spec_max;        // second half: transposed output
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * f.real_elems, hipMemcpyHostToDevice, s));
+    if (c->generic) {
+        g_rfft2(s, 1, which ? c->gpol : c->gimg, d_in, f.real_elems, f.g.rows, nullptr, L.tmpA, c->spec_max, nullptr);
+    } else {
     launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, f.g.rows, nullptr, L.tmpA, c->spec_max);
     launch_B_fwd(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
+    }
     launch_transpose_c(s, L.tmpA, d_out, f.g.hr, f.g.cols);
     HIP_TRY(c, hipMemcpyAsync(xf_out, d_out, sizeof(float2) * f.spec_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
@@ -1630,9 +1715,13 @@ int nik_dbg_ifft(nik_ctx* c, int which, const float* xf, float* x_out) {
     float2* scratch = reinterpret_cast<float2*>(c->d_scratch);
     HIP_TRY(c, hipMemcpyAsync(scratch, xf, sizeof(float2) * f.spec_elems, hipMemcpyHostToDevice, s));
     launch_transpose_c(s, scratch, L.tmpA, f.g.cols, f.g.hr);
-    launch_B_inv(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.gbuf, c->spec_max);
     float* dst = reinterpret_cast<float*>(L.kbuf);
+    if (c->generic) {
+        g_irfft2(s, 1, which ? c->gpol : c->gimg, L.tmpA, c->spec_max, nullptr, dst, f.real_elems, f.g.rows);
+    } else {
+    launch_B_inv(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.gbuf, c->spec_max);
     launch_A_inv_real(s, 1, f.g, f.t, L.gbuf, c->spec_max, dst, f.real_elems);
+    }
     HIP_TRY(c, hipMemcpyAsync(x_out, dst, sizeof(float) * f.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -1652,7 +1741,10 @@ int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     if (!c->rot_one) HIP_TRY(c, hipMalloc(&c->rot_one, sizeof(int) * terms.size()));
     HIP_TRY(c, hipMemcpyAsync(c->rot_one, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
     const int* d_slot = c->rot_one + terms.size() - 2; const int* d_index = d_slot + 1;
-    if (c->slot_kind[fr] & 1)
+    if (c->generic)
+        g_rotate(s, 1, (c->slot_kind[fr] & 1) ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, d_slot, c->rot_one, d_index,
+                 c->d_scratch, c->img.real_elems, c->H, c->W);
+    else if (c->slot_kind[fr] & 1)
         launch_A_fwd_rot8(s, 1, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, d_slot, c->rot_one, d_index, L.tmpA, c->spec_max, c->d_scratch);
     else
         launch_A_fwd_rot(s, 1, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, d_slot, c->rot_one, d_index, L.tmpA, c->spec_max, c->d_scratch);
@@ -1671,9 +1763,14 @@ int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     float* d_out = reinterpret_cast<float*>(L.gbuf);
     float* d_in = c->d_scratch;
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
+    if (c->generic) {
+        g_shift_fix(s, 1, d_in, c->img.real_elems, L.splane, c->s_elems, c->H, c->W);
+        g_polar(s, 1, L.splane, c->s_elems, c->g_polar_map, d_out, c->pol.real_elems, c->H, c->PD, c->PC);
+    } else {
     launch_make_shifted(s, d_in, L.splane, c->H, c->W);
     launch_fix_zero(s, 1, L.splane, c->s_elems, c->H, c->W);
     launch_A_fwd_polar(s, 1, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max, d_out);
+    }
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(float) * c->pol.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());
@@ -1689,6 +1786,7 @@ int nik_dbg_response(nik_ctx* c, int which, nik_frame key, nik_frame cur, int de
     if (!c || !g || (which != 0 && which != 1)) return NIK_ERR_INVALID_ARG;
     int rc;
     if ((rc = check_kernel(c)) || (rc = nik_synchronize(c)) || (rc = check_slot(c, key, true)) || (rc = check_slot(c, cur, true))) return rc;
+    if (c->generic) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "nik_dbg_response is a tap of the tiled kernels (this context runs the any-size family)");
     if (c->kzz_cache && (rc = ensure_kzz(c, 1, &key))) return rc;
     Lane& L = c->lanes[0]; hipStream_t s = L.stream;
     if ((rc = begin_call(c, L)) || (rc = depend_on_slot(c, L, 0, key)) || (rc = depend_on_slot(c, L, 0, cur))) return rc;

@@ -65,7 +65,8 @@ def test_argument_validation_precedes_device_use(lib_path):
     cfg = N.default_config()
     assert L.nik_create(None, 480, 640, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_INVALID_ARG
     assert L.nik_create(ctypes.byref(cfg), 481, 640, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_UNSUPPORTED_SIZE
-    assert L.nik_create(ctypes.byref(cfg), 480, 642, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_UNSUPPORTED_SIZE
+    # (480 x 642 is a valid geometry since round 4: it runs the any-size kernel family; lengths beyond 8192 are refused)
+    assert L.nik_create(ctypes.byref(cfg), 480, 16384, 1, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_UNSUPPORTED_SIZE
     assert L.nik_create(ctypes.byref(cfg), 480, 640, 0, 1, 0, ctypes.byref(ctx)) == N.NIK_ERR_INVALID_ARG
     assert b"even" in L.nik_last_error(None) or b"positive" in L.nik_last_error(None)
     assert L.nik_synchronize(None) == N.NIK_ERR_INVALID_ARG
