@@ -861,6 +861,12 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #ifndef KCC_U8_TPW
 #define KCC_U8_TPW 2
 #endif
+// 1: file the image in the u8 frame store by whole rows (full-line writes) instead of tile by tile.  Measured (round 4): the
+// kernel's write traffic falls to its nominal bytes, its TIME rises -- 0.119 -> 0.127 ms at 640x480, 0.316 -> 0.327 ms at
+// 1280x720 (the extra row loads and stores sit in front of the first tile's transform) -- so the tile-wise copy stays.
+#ifndef KCC_U8_COPY_ROWS
+#define KCC_U8_COPY_ROWS 0
+#endif
 template <int HH>
 // (the register prefetch of the next tile needs ~123 VGPRs at 240 points and ~150 at 360: never ask for more waves per
 // SIMD than that leaves room for -- a 128-register cap made the 360-point kernel spill 33 dwords: 0.396 -> 0.331 ms at HD)
@@ -888,6 +894,23 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
         }
     };
     fetch(cur, g * tpw * A_LX, threadIdx.x);
+#if KCC_U8_COPY_ROWS
+    // The image's copy in the u8 frame store (the de-rotation of ComputePose reads it from there) is written by ROWS, not by
+    // tiles: the workgroups of an image share its rows out, each copies whole rows in 16-byte pieces that are contiguous
+    // across the lanes -- full-line writes.  (Filed tile by tile -- 16 bytes of every row per tile -- the stores were partial
+    // lines: the u8 kernel wrote 1.45x its nominal bytes)  The source rows are the ones the image's tiles are
+    // reading anyway on the same XCD: the second read is an L2 hit.
+    if (keep && !ABL(a, 64)) {
+        const int ng = (a.cols / A_LX) / tpw, per = (ROWS + ng - 1) / ng, r0 = g * per, r1 = min(ROWS, r0 + per);
+        const int cpr = a.cols / 16 + 1;                      // 16-byte pieces per row: W / 16 of the image + the wrap columns
+        const int total = (r1 - r0) * cpr;
+        for (int i = (int)threadIdx.x; i < total; i += C::NT) {
+            const int r = r0 + i / cpr, ch = i % cpr;
+            const uint4 v = *reinterpret_cast<const uint4*>(in + (size_t)r * a.src8_pitch + (ch == cpr - 1 ? 0 : 16 * ch));
+            *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + 16 * ch) = v;
+        }
+    }
+#endif
     for (int t = 0; t < tpw; ++t) {
         const int bx = g * tpw + t, x0 = bx * A_LX;
         // Everything per-thread is re-derived per tile from an opaque copy of the thread index, and the twiddle tables are
@@ -904,7 +927,7 @@ __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC
             const int r = tid + it * C::NT;
             if (r < ROWS) {
                 st[r] = cur[it];
-                if (keep && !ABL(a, 64)) {
+                if (!KCC_U8_COPY_ROWS && keep && !ABL(a, 64)) {
                     *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + x0) = cur[it];
                     if (bx == 0) *reinterpret_cast<uint4*>(keep + (size_t)r * a.dst8_pitch + a.cols) = cur[it];   // wrap columns
                 }
