@@ -120,3 +120,18 @@ def test_any_size_family_agrees_with_the_tiled_kernels_at_640x480():
             assert ok, "%s pair %d %s: %s" % (fam, i, motions[i], msg)
         assert rg[i]["trans_row"] == rt[i]["trans_row"] and rg[i]["trans_col"] == rt[i]["trans_col"]
         assert rg[i]["rot_col"] == rt[i]["rot_col"] and (rg[i]["rot_row"] - rt[i]["rot_row"]) % (PD // 2) == 0
+
+
+@pytest.mark.timeout(1800)
+def test_callers_of_the_boundary_on_the_any_size_family():
+    """the sequence driver, the key-frame map / loop closure, the coarse-to-fine pyramid and the multi-GPU group run unchanged on
+    top of the any-size family: their own GPU tests, re-run in a process where every context is forced onto it ($NIK_GENERIC=1)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIK_GENERIC="1")
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "tests/test_tracker.py", "tests/test_map.py", "tests/test_pyramid.py",
+                        "tests/test_pipeline.py", "tests/test_camera.py", "tests/test_group.py::test_local_group_of_one_gpu_equals_direct_calls"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1700)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
