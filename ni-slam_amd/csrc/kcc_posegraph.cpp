@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -252,7 +253,8 @@ static kcc_pg::DevProblem* to_device(const Problem& P, int device, std::string& 
     return kcc_pg::dev_create(device, P.n, P.dim, de, P.col, err);
 }
 
-// device < 0: residuals and normal equations on the host; else on that HIP device (the solve stays on the host)
+// device < 0: residuals, normal equations and the damped solve on the host; else all three on that HIP device
+// ($NIK_PG_HOST_SOLVE=1: only the linearisation on the device, the solve on the host as in round 3)
 static int optimize(int device, int n_poses, const int32_t* ids, double* poses, int n_constraints,
                     const nik_pg_constraint* cons, int max_iterations, nik_pg_summary* summary) {
     if (n_poses < 0 || n_constraints < 0 || (n_poses > 0 && (!ids || !poses)) || (n_constraints > 0 && !cons)) return NIK_ERR_INVALID_ARG;
@@ -268,6 +270,7 @@ static int optimize(int device, int n_poses, const int32_t* ids, double* poses, 
         if (!dev) return NIK_ERR_HIP;
     }
     struct Guard { kcc_pg::DevProblem* d; ~Guard() { kcc_pg::dev_destroy(d); } } guard{ dev };
+    const bool host_solve = getenv("NIK_PG_HOST_SOLVE") && atoi(getenv("NIK_PG_HOST_SOLVE")) != 0;
     // linearise at xs: residual cost, and (want_normal) the Gauss-Newton blocks into N
     std::vector<double> r_, J_;
     auto linearize = [&](const std::vector<double>& xs, double& cost_out, Normal* N) -> bool {
@@ -301,7 +304,17 @@ static int optimize(int device, int n_poses, const int32_t* ids, double* poses, 
                 const double d2 = std::min(std::max(N.diag[(size_t)b * 9 + 4 * i], 1e-6 * 1e-6), 1e32 * 1e32);   // D^2, D clamped to [1e-6, 1e32]
                 damp[3 * b + i] = d2 / radius;
             }
-        if (!solve(P, N, damp, step)) { radius /= decrease; decrease *= 2; if (radius < 1e-32) { sm.termination = NIK_PG_FAILURE; break; } continue; }
+        bool solved;
+        if (dev && !host_solve) {
+            // the damped step on the device too (k_pg_pcg: the blocks of the current point are still there)
+            step.assign(P.dim, 0.0);
+            const int sr = kcc_pg::dev_solve(dev, damp.data(), step.data(), nullptr);
+            if (sr < 0) return NIK_ERR_HIP;
+            solved = sr == 0;
+        } else {
+            solved = solve(P, N, damp, step);
+        }
+        if (!solved) { radius /= decrease; decrease *= 2; if (radius < 1e-32) { sm.termination = NIK_PG_FAILURE; break; } continue; }
         // model decrease: -(g^T s + 0.5 s^T H s) with H = J^T J
         std::vector<double> Hs, zero(P.dim, 0.0);
         apply(P, N, zero, step, Hs);

@@ -138,8 +138,11 @@ def test_host_linearisation_matches_the_independent_jacobian():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,loops,seed", [(12, [(0, 11), (3, 9)], 1), (300, [(0, 299), (20, 180), (100, 250), (50, 290), (130, 140)], 3)])
+@pytest.mark.parametrize("n,loops,seed", [(12, [(0, 11), (3, 9)], 1), (300, [(0, 299), (20, 180), (100, 250), (50, 290), (130, 140)], 3),
+                                          (1500, [(0, 1499), (100, 900), (400, 1300), (50, 1450), (700, 720), (10, 600)], 7)])
 def test_device_linearisation_and_solve_match_the_host(n, loops, seed):
+    """device = 0: residuals, normal equations AND the damped solve (block-Jacobi PCG in one workgroup, k_pg_pcg) on the GPU;
+    device = -1: all on the host (dense Cholesky up to 256 free poses, PCG beyond)"""
     N = nik()
     ids, guess, cons = make_graph(n, seed, loops)
     ch, gh, dh = N.pose_graph_linearize(ids, guess, cons, device=-1)
