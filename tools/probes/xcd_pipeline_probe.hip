@@ -40,7 +40,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int NK = 361, NL = 480;                 // half-spectrum rows x columns of the 720 x 480 polar plane (complex)
 constexpr int PLANE = NK * NL;                    // float2 elements per plane
 constexpr int ZZC = 252;                          // stored columns of the Hermitian-half zz plane (kcc: zz_half_columns)
-constexpr int LK1 = 5, LK3 = 6, LXA = 12;         // rows per B tile (phase 1 / 3), columns per A tile (phases 2 / 4)
+#ifndef PROBE_LK1
+#define PROBE_LK1 5
+#endif
+#ifndef PROBE_LK3
+#define PROBE_LK3 6
+#endif
+#ifndef PROBE_LXA
+#define PROBE_LXA 12
+#endif
+constexpr int LK1 = PROBE_LK1, LK3 = PROBE_LK3, LXA = PROBE_LXA;   // rows per B tile (phase 1 / 3), columns per A tile (phases 2 / 4); -D overrides: tile-size study
 constexpr int T1 = (NK + LK1 - 1) / LK1;          // 73 tiles
 constexpr int T2Z = ZZC / LXA, T2X = NL / LXA;    // 21 + 40 tiles
 constexpr int T2 = T2Z + T2X;
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(NT, PROBE_WPS) void k_generic(const Params* __restr
         const unsigned t = s_ticket;
         if (t >= (unsigned)len) break;
         const unsigned w = list[t];
-        const int tile = w & 127, ph = ((w >> 7) & 3) + 1, item = __builtin_amdgcn_readfirstlane((int)(w >> 9));
+        const int tile = w & 255, ph = ((w >> 8) & 3) + 1, item = __builtin_amdgcn_readfirstlane((int)(w >> 10));
         if (ph > 1) {
             if (threadIdx.x == 0) wait_ge(f.done + item * 4 + (ph - 2), ph == 2 ? T1 : ph == 3 ? T2 : T3, p.err, f.census + 8 + xcc);
             __syncthreads();
@@ -374,7 +383,7 @@ int main(int argc, char** argv) {
             std::vector<std::pair<int, int>> groups;         // (item, phase-1) issued in this slot, oldest phase first
             for (int ph = 3; ph >= 0; --ph) { const int r = sl - G * ph; if (r >= 0 && r % D == 0 && r / D < (int)items.size()) groups.push_back({ items[r / D], ph }); }
             int mt = 0; for (auto& g : groups) mt = std::max(mt, tiles_of[g.second]);
-            for (int t = 0; t < mt; ++t) for (auto& g : groups) if (t < tiles_of[g.second]) list.push_back(((unsigned)g.first << 9) | ((unsigned)g.second << 7) | (unsigned)t);
+            for (int t = 0; t < mt; ++t) for (auto& g : groups) if (t < tiles_of[g.second]) list.push_back(((unsigned)g.first << 10) | ((unsigned)g.second << 8) | (unsigned)t);
         }
         gq.list_len[x] = (int)list.size() - gq.list_off[x];
       } }
