@@ -94,7 +94,9 @@ struct nik_ctx {
 
     Family img, pol;
     // any-size fallback (kcc_generic.hip): set when the geometry is outside the tiled kernels' instantiated set (or $NIK_GENERIC=1)
-    bool generic = false; GFamily gimg{}, gpol{}; float2* g_tw[4] = { nullptr, nullptr, nullptr, nullptr }; uint32_t* g_polar_map = nullptr;
+    bool generic = false;          // either family below is on the any-size kernels (work planes allocated; no graphs / Kzz cache / deferred passes)
+    bool gen_img = false, gen_pol = false;   // per plane family: a 640x480 camera with a 720x64 polar plane keeps the tiled image kernels
+    GFamily gimg{}, gpol{}; float2* g_tw[4] = { nullptr, nullptr, nullptr, nullptr }; uint32_t* g_polar_map = nullptr;
     // keyframe store (reference Frame: _frame, _fft_result, _fft_polar)
     // The image of a frame lives as u8 (row-major, what the u8 entry points receive) or as f32 (column-major, what the
     // reference's ArrayXXf entry points hand over); slot_kind says which copies are valid.
@@ -201,7 +203,7 @@ int upload_table(nik_ctx* c, const std::vector<float2>& h, float2** d) {
 int family_init(nik_ctx* c, Family& f, int rows, int cols) {
     f.g.rows = rows; f.g.cols = cols; f.g.hr = rows / 2 + 1;
     f.real_elems = (size_t)rows * cols; f.spec_elems = (size_t)f.g.hr * cols;
-    if (c->generic) return NIK_OK;                           // (run-time plans: generic_init)
+    if ((&f == &c->img) ? c->gen_img : c->gen_pol) return NIK_OK;   // (run-time plans: generic_init)
     if (kfwd_parts(f.g, false) > KCC_MAXPARTS) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%d x %d: more running-max parts than KCC_MAXPARTS", rows, cols);
     const int h = rows / 2;
     const PlanDesc ph = plan_desc(h), pc = plan_desc(cols);
@@ -226,6 +228,7 @@ int generic_init(nik_ctx* c) {
     c->gpol.g = c->pol.g; c->gpol.prow = gplan_make(c->PD, c->g_tw[2]); c->gpol.pcol = gplan_make(c->PC, c->g_tw[3]);
     for (const GPlan* p : { &c->gimg.prow, &c->gimg.pcol, &c->gpol.prow, &c->gpol.pcol })
         if (p->nr == 0) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "FFT length %d has more prime factors than the run-time plan holds", p->n);
+    if (!c->gen_pol) return NIK_OK;
     std::vector<uint32_t> map; std::string err;
     if (build_polar_map(c->H, c->W, c->PD, c->PC, map, err)) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
     HIP_TRY(c, hipMalloc(&c->g_polar_map, sizeof(uint32_t) * map.size()));
@@ -439,7 +442,7 @@ int ensure_f32_images(nik_ctx* c, Lane& L, int li, int n, const nik_frame* slots
     if (!k) return NIK_OK;
     int rc = upload_idx(c, L, IX_CVT, k);
     if (rc) return rc;
-    if (c->generic) g_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
+    if (c->gen_img) g_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
     else launch_cvt_u8(L.stream, k, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_CVT), c->arena_img, c->H, c->W, c->img_pitch);
     // published as a slot write of this lane: other lanes order their reads of the new planes after it
     L.write_seq += 1;
@@ -494,54 +497,55 @@ inline double Cb(const Family& f) { return 8.0 * (double)f.spec_elems; }     // 
 // defer_polar_B: leave the polar spectrum's second (radius) pass to the caller -- the pose that follows fuses it into
 // its first kernel (fwd_mul_inv), which also writes the finished spectrum to the frame store.  L.tmpA then holds the
 // half-transformed polar spectra.
-// the same for a context of the any-size family (kcc_generic.hip): every stage its own launch, planes in the lane's buffers
-void enqueue_intermedium_generic(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8) {
-    hipStream_t s = L.stream;
-    const int* dst = didx(L, IX_DST);
-    const Family& I = c->img; const Family& P = c->pol;
-    const size_t RS = 2 * c->r_elems;                        // real work planes per item: [2][r_elems]
-    if (d_u8) {
-        if (c->ud_map1) { launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W); d_u8 = L.u8tmp; }
-        Stage st(c, L, "kg_intermedium", n * (double)(c->img.real_elems));
-        g_u8_load(s, n, d_u8, c->img.real_elems, L.rbuf, RS, c->arena_u8, c->u8_stride, c->u8_pitch, dst, c->H, c->W);
-        g_rfft2(s, n, c->gimg, L.rbuf, RS, c->H, nullptr, c->arena_F, I.spec_elems, dst);
-    } else {
-        g_rfft2(s, n, c->gimg, c->arena_img, c->img_stride, c->img_pitch, dst, c->arena_F, I.spec_elems, dst);
-    }
-    g_abs(s, n, c->arena_F, I.spec_elems, dst, L.gbuf, c->spec_max, I.spec_elems);                // fft_result.abs()           (:92)
-    g_irfft2(s, n, c->gimg, L.gbuf, c->spec_max, nullptr, L.rbuf + c->r_elems, RS, c->H);         // the zero-phase image       (:92)
-    g_shift_fix(s, n, L.rbuf + c->r_elems, RS, L.splane, c->s_elems, c->H, c->W);                 // RemoveZeroComponent, fftshift (:93-94)
-    g_polar(s, n, L.splane, c->s_elems, c->g_polar_map, L.rbuf, RS, c->H, c->PD, c->PC);          // polar                      (:94)
-    g_rfft2(s, n, c->gpol, L.rbuf, RS, c->PD, nullptr, c->arena_P, P.spec_elems, dst);
-}
-
 void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool defer_polar_B = false) {
-    if (c->generic) { enqueue_intermedium_generic(c, L, n, d_u8); return; }
     hipStream_t s = L.stream;
     const int* dst = didx(L, IX_DST);
     const Family& I = c->img; const Family& P = c->pol;
-    if (d_u8) {
-        const double N = (double)c->img.real_elems;
-        if (c->ud_map1) {
-            Stage st(c, L, "k_undistort_u8", n * 2.0 * N + 6.0 * N);
-            launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W);
-            d_u8 = L.u8tmp;
-        }
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "u8", a_tag(c, I)).c_str(), n * (N + Cb(I)));
-        launch_A_fwd_u8(s, n, c->img.g, c->img.t, d_u8, c->img.real_elems, c->W, c->arena_u8, c->u8_stride, c->u8_pitch, dst, L.tmpA, c->spec_max);
-    } else {
-        Stage st(c, L, kname("kA_fwd", c->H / 2, "plane", a_tag(c, I)).c_str(), n * (Rb(I) + Cb(I)));
-        launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max);
+    const size_t RS = 2 * c->r_elems;                        // any-size kernels: real work planes per item, [2][r_elems]
+    if (d_u8 && c->ud_map1) {
+        Stage st(c, L, "k_undistort_u8", n * 2.0 * (double)I.real_elems + 6.0 * (double)I.real_elems);
+        launch_undistort_u8(s, n, d_u8, L.u8tmp, c->ud_map1, c->ud_map2, c->H, c->W);
+        d_u8 = L.u8tmp;
     }
-    // IFFT(|F|) is real and even and the polar gather only reads the inscribed circle: columns |c| <= Rmax + 1 suffice
-    const int need = c->zz_half ? std::min(c->H / 2, c->W / 2) + 1 : 0;
-    { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv", b_tag(c, I)).c_str(), n * 3 * Cb(I));
-      launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
-                           L.gbuf, c->spec_max, need); }
-    { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)));
-      launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need, c->fuse_fix_zero); }
-    // RemoveZeroComponent: inside that kernel (mirrored half-plane form), else a launch of its own
-    if (!(need > 0 && c->fuse_fix_zero)) launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
+    // ---- image family: fft_result, the zero-phase image, RemoveZeroComponent + fftshift -> the shifted plane S (:91-94)
+    if (c->gen_img) {
+        // any-size kernels (kcc_generic.hip): every stage its own launch, planes in the lane's work buffers
+        Stage st(c, L, "kg_intermedium_image", n * (double)I.real_elems);
+        if (d_u8) {
+            g_u8_load(s, n, d_u8, I.real_elems, L.rbuf, RS, c->arena_u8, c->u8_stride, c->u8_pitch, dst, c->H, c->W);
+            g_rfft2(s, n, c->gimg, L.rbuf, RS, c->H, nullptr, c->arena_F, I.spec_elems, dst);
+        } else {
+            g_rfft2(s, n, c->gimg, c->arena_img, c->img_stride, c->img_pitch, dst, c->arena_F, I.spec_elems, dst);
+        }
+        g_abs(s, n, c->arena_F, I.spec_elems, dst, L.gbuf, c->spec_max, I.spec_elems);
+        g_irfft2(s, n, c->gimg, L.gbuf, c->spec_max, nullptr, L.rbuf + c->r_elems, RS, c->H);
+        g_shift_fix(s, n, L.rbuf + c->r_elems, RS, L.splane, c->s_elems, c->H, c->W);
+    } else {
+        if (d_u8) {
+            const double N = (double)I.real_elems;
+            Stage st(c, L, kname("kA_fwd", c->H / 2, "u8", a_tag(c, I)).c_str(), n * (N + Cb(I)));
+            launch_A_fwd_u8(s, n, c->img.g, c->img.t, d_u8, c->img.real_elems, c->W, c->arena_u8, c->u8_stride, c->u8_pitch, dst, L.tmpA, c->spec_max);
+        } else {
+            Stage st(c, L, kname("kA_fwd", c->H / 2, "plane", a_tag(c, I)).c_str(), n * (Rb(I) + Cb(I)));
+            launch_A_fwd_plane(s, n, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, dst, L.tmpA, c->spec_max);
+        }
+        // IFFT(|F|) is real and even and the polar gather only reads the inscribed circle: columns |c| <= Rmax + 1 suffice
+        const int need = c->zz_half ? std::min(c->H / 2, c->W / 2) + 1 : 0;
+        { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv", b_tag(c, I)).c_str(), n * 3 * Cb(I));
+          launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
+                               L.gbuf, c->spec_max, need); }
+        { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)));
+          launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need, c->fuse_fix_zero); }
+        // RemoveZeroComponent: inside that kernel (mirrored half-plane form), else a launch of its own
+        if (!(need > 0 && c->fuse_fix_zero)) launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
+    }
+    // ---- polar family: polar(S) and its spectrum (:94)
+    if (c->gen_pol) {
+        Stage st(c, L, "kg_intermedium_polar", n * (double)P.real_elems);
+        g_polar(s, n, L.splane, c->s_elems, c->g_polar_map, L.rbuf, RS, c->H, c->PD, c->PC);
+        g_rfft2(s, n, c->gpol, L.rbuf, RS, c->PD, nullptr, c->arena_P, P.spec_elems, dst);
+        return;
+    }
     { Stage st(c, L, kname("kA_fwd", c->PD / 2, "polar", a_tag(c, P)).c_str(), n * (Rb(I) + Cb(P)));
       launch_A_fwd_polar(s, n, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max); }
     if (defer_polar_B) return;
@@ -556,8 +560,8 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     hipStream_t s = L.stream;
     const double xs_bytes = xstore ? n * Cb(f) : 0.0;        // x_fwd with xstore: the forward spectrum is written out too
     const size_t item_stride = 2 * c->spec_max, plane_stride = c->spec_max;
-    if (c->generic) {
-        // any-size family: Kzz and Kxz side by side as 2n planes (x_fwd never set: generic contexts do not defer passes)
+    if ((&f == &c->pol) ? c->gen_pol : c->gen_img) {
+        // any-size family: Kzz and Kxz side by side as 2n planes (x_fwd never set: such contexts do not defer passes)
         const GFamily& gf = (&f == &c->pol) ? c->gpol : c->gimg;
         Stage st(c, L, (&f == &c->pol) ? "kg_estimate_rot" : "kg_estimate_trans", 0.0);
         if (c->cfg.kernel == 1) launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
@@ -629,7 +633,7 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
                      c->arena_P, c->pol.spec_elems, didx(L, IX_KEY), L.rot_res, didx(L, IX_ROTIDX), n_hyp, nullptr, 0, nullptr, wrot);
     // translation items (one per pair and hypothesis); their index arrays were staged by stage_pose_indices()
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
-    if (c->generic) {
+    if (c->gen_img) {
         // RotateArray + FFT, unfused: the rotated planes, then their spectra in tmpA
         g_rotate(s, nt, img_u8 ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG),
                  c->rot_tab, didx(L, IX_ROTIDX), L.rbuf, 2 * c->r_elems, c->H, c->W);
@@ -766,9 +770,11 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     // 16) and an aspect ratio within 2:1 (every de-rotated source coordinate then stays within one period: single-step
     // BORDER_WRAP).  Every other geometry the reference accepts (correlation_flow.cc:53-77: any size with even rows) runs the
     // any-size family (kcc_generic.hip): slower, same results.  $NIK_GENERIC=1 forces it (tests compare the two families).
-    const bool tiled = fft_half_supported(H / 2) && fft_half_supported(PD / 2) && fft_line_supported(W) && fft_line_supported(PC) &&
-                       W % 16 == 0 && PC % 16 == 0 && !(H / 2 + 2 > W || W / 2 + 2 > H);
-    const bool generic = !tiled || (getenv("NIK_GENERIC") && atoi(getenv("NIK_GENERIC")) != 0);
+    // The choice is per plane family: a 640 x 480 camera with a 720 x 64 polar plane keeps the tiled image kernels.
+    const int force = getenv("NIK_GENERIC") ? atoi(getenv("NIK_GENERIC")) : 0;      // bit 0: image family, bit 1: polar family; 1 = both (tests)
+    const bool gen_img = !(fft_half_supported(H / 2) && fft_line_supported(W) && W % 16 == 0 && !(H / 2 + 2 > W || W / 2 + 2 > H)) || force == 1 || (force & 4);
+    bool gen_pol = !(fft_half_supported(PD / 2) && fft_line_supported(PC) && PC % 16 == 0) || force == 1 || (force & 2);
+    const bool generic = gen_img || gen_pol;
     if (generic && (std::max({ H, W, PD, PC }) > 8192 || H < 4 || W < 4 || PD < 4 || PC < 4))
         return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "any-size path: lengths from 4 to 8192 (got %dx%d / polar %dx%d)", H, W, PD, PC);
     int ndev = 0;
@@ -779,7 +785,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->cfg = *cfg; c->cfg.height = H; c->cfg.width = W;      // correlation_flow.cc:40-41
     c->H = H; c->W = W; c->PD = PD; c->PC = PC; c->max_batch = max_batch; c->max_frames = max_frames; c->device = device;
     c->max_items = 2 * max_batch;
-    c->generic = generic;
+    c->generic = generic; c->gen_img = gen_img; c->gen_pol = gen_pol;
     auto bail = [&](int rc) { g_create_error = c->err; nik_destroy(c); return rc; };
 #define TRY_C(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { fail(c, NIK_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return bail(NIK_ERR_HIP); } } while (0)
     TRY_C(hipSetDevice(device));
@@ -788,8 +794,11 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->spec_max = std::max(c->img.spec_elems, c->pol.spec_elems);
     c->s_elems = (size_t)(W + 1) * (H + 2);
     c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
-    c->partial_stride = generic ? std::max(g_argmax_blocks(H, W), g_argmax_blocks(PD, PC)) : std::max(argmax_blocks(c->img.g), argmax_blocks(c->pol.g));
-    if (generic && (rc = generic_init(c))) return bail(rc);
+    // the tiled polar gather stages annulus segments of THIS image geometry in LDS: an image size whose segments do not fit
+    // sends the polar family to the any-size kernels as well
+    if (!c->gen_pol && build_polar_table(c)) { c->gen_pol = true; c->generic = true; c->err.clear(); }
+    if (c->generic && (rc = generic_init(c))) return bail(rc);
+    c->partial_stride = std::max(c->gen_img ? g_argmax_blocks(H, W) : argmax_blocks(c->img.g), c->gen_pol ? g_argmax_blocks(PD, PC) : argmax_blocks(c->pol.g));
     // column pitch: >= H + 4 (wrap rows), a multiple of 32 floats (columns start on 128-byte lines) and an ODD multiple
     // (no power-of-two stride across HBM channels)
     c->img_pitch = ((H + 4 + 31) / 32) * 32;
@@ -826,8 +835,8 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if ((rc = lane_alloc(c, c->lanes[0], nl))) return bail(rc);
     TRY_C(hipMalloc(&c->d_u8, (size_t)H * W));
     TRY_C(hipMalloc(&c->d_scratch, sizeof(float) * std::max(c->img.real_elems, 2 * c->spec_max) * 2));
-    if (generic) { c->fuse_polar = false; c->kzz_cache = false; c->graph_max = 0; }    // (the any-size family has no fused / cached / captured forms)
-    if ((!generic && (rc = build_polar_table(c))) || (rc = build_rot_table(c))) return bail(rc);
+    if (c->generic) { c->fuse_polar = false; c->kzz_cache = false; c->graph_max = 0; }    // (the any-size family has no fused / cached / captured forms)
+    if ((rc = build_rot_table(c))) return bail(rc);
     TRY_C(hipDeviceSynchronize());
 #undef TRY_C
     *out = c;
@@ -867,7 +876,7 @@ int nik_get_dims(const nik_ctx* c, int dims[6]) {
     return NIK_OK;
 }
 int nik_device(const nik_ctx* c) { return c ? c->device : -1; }
-int nik_is_generic(const nik_ctx* c) { return c ? (c->generic ? 1 : 0) : NIK_ERR_INVALID_ARG; }
+int nik_is_generic(const nik_ctx* c) { return c ? ((c->gen_img ? 1 : 0) | (c->gen_pol ? 2 : 0)) : NIK_ERR_INVALID_ARG; }
 void* nik_stream(const nik_ctx* c) { return c ? (void*)c->lanes[0].stream : nullptr; }
 
 int nik_set_streams(nik_ctx* c, int n) {
@@ -1036,14 +1045,17 @@ int nik_upload_u8_async(nik_ctx* c, int n, const uint8_t* gray, int stride, size
     }
     const size_t fb = (size_t)c->H * c->W;
     hipPointerAttribute_t at{};
-    const bool pinned = hipPointerGetAttributes(&at, gray) == hipSuccess && at.type == hipMemoryTypeHost;
+    // pinned host memory -- and anything else the copy engine can read by itself (device, managed) -- is copied directly; only
+    // plain pageable memory is staged
+    const bool known = hipPointerGetAttributes(&at, gray) == hipSuccess;
     (void)hipGetLastError();                                  // (an unregistered pointer reports an error: not ours)
+    const bool pinned = known && (at.type == hipMemoryTypeHost || at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged);
     if (pinned) {
         if (frame_stride == (size_t)stride * (size_t)c->H)   // the frames form one tall image: a single 2-D copy
-            HIP_TRY(c, hipMemcpy2DAsync(d_dst, c->W, gray, stride, c->W, (size_t)c->H * n, hipMemcpyHostToDevice, c->up_stream));
+            HIP_TRY(c, hipMemcpy2DAsync(d_dst, c->W, gray, stride, c->W, (size_t)c->H * n, hipMemcpyDefault, c->up_stream));
         else
             for (int i = 0; i < n; ++i)
-                HIP_TRY(c, hipMemcpy2DAsync(d_dst + (size_t)i * fb, c->W, gray + (size_t)i * frame_stride, stride, c->W, c->H, hipMemcpyHostToDevice, c->up_stream));
+                HIP_TRY(c, hipMemcpy2DAsync(d_dst + (size_t)i * fb, c->W, gray + (size_t)i * frame_stride, stride, c->W, c->H, hipMemcpyDefault, c->up_stream));
     } else {
         const int per = 8;                                    // frames per staging piece
         if (c->up_pin_bytes < fb * per) {
@@ -1105,7 +1117,7 @@ int nik_intermedium_f32(nik_ctx* c, const float* image, nik_frame dst) {
     if ((rc = begin_call(c, L)) || (rc = depend_for_write(c, L, 0, dst))) return rc;
     HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)dst * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
                                 sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, L.stream));
-    if (!c->generic) launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);   // (the any-size rotate wraps by index)
+    if (!c->gen_img) launch_img_wrap(L.stream, c->arena_img + (size_t)dst * c->img_stride, c->H, c->W, c->img_pitch);   // (the any-size rotate wraps by index)
     hidx(L, IX_DST)[0] = dst;
     if ((rc = upload_idx(c, L, IX_DST, 1))) return rc;
     enqueue_intermedium(c, L, 1, nullptr);
@@ -1148,7 +1160,7 @@ int nik_frame_import(nik_ctx* c, nik_frame f, const float* image, const float* f
     if (image) {
         HIP_TRY(c, hipMemcpy2DAsync(c->arena_img + (size_t)f * c->img_stride, sizeof(float) * c->img_pitch, image, sizeof(float) * c->H,
                                     sizeof(float) * c->H, c->W, hipMemcpyHostToDevice, s));
-        if (!c->generic) launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
+        if (!c->gen_img) launch_img_wrap(s, c->arena_img + (size_t)f * c->img_stride, c->H, c->W, c->img_pitch);
         c->slot_ready[f] |= 1; c->slot_kind[f] = 2;
     }
     if (fft_result) {
@@ -1693,7 +1705,7 @@ int nik_dbg_fft(nik_ctx* c, int which, const float* x, float* xf_out) {
     float* d_in = c->d_scratch;                                                   // first half: real input
     float2* d_out = reinterpret_cast<float2*>(c->d_scratch) + c->spec_max;        // second half: transposed output
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * f.real_elems, hipMemcpyHostToDevice, s));
-    if (c->generic) {
+    if (which ? c->gen_pol : c->gen_img) {
         g_rfft2(s, 1, which ? c->gpol : c->gimg, d_in, f.real_elems, f.g.rows, nullptr, L.tmpA, c->spec_max, nullptr);
     } else {
     launch_A_fwd_plane(s, 1, f.g, f.t, d_in, f.real_elems, f.g.rows, nullptr, L.tmpA, c->spec_max);
@@ -1716,7 +1728,7 @@ int nik_dbg_ifft(nik_ctx* c, int which, const float* xf, float* x_out) {
     HIP_TRY(c, hipMemcpyAsync(scratch, xf, sizeof(float2) * f.spec_elems, hipMemcpyHostToDevice, s));
     launch_transpose_c(s, scratch, L.tmpA, f.g.cols, f.g.hr);
     float* dst = reinterpret_cast<float*>(L.kbuf);
-    if (c->generic) {
+    if (which ? c->gen_pol : c->gen_img) {
         g_irfft2(s, 1, which ? c->gpol : c->gimg, L.tmpA, c->spec_max, nullptr, dst, f.real_elems, f.g.rows);
     } else {
     launch_B_inv(s, 1, f.g, f.t, L.tmpA, c->spec_max, L.gbuf, c->spec_max);
@@ -1741,7 +1753,7 @@ int nik_dbg_rotate(nik_ctx* c, nik_frame fr, int degree2, float* out) {
     if (!c->rot_one) HIP_TRY(c, hipMalloc(&c->rot_one, sizeof(int) * terms.size()));
     HIP_TRY(c, hipMemcpyAsync(c->rot_one, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
     const int* d_slot = c->rot_one + terms.size() - 2; const int* d_index = d_slot + 1;
-    if (c->generic)
+    if (c->gen_img)
         g_rotate(s, 1, (c->slot_kind[fr] & 1) ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, d_slot, c->rot_one, d_index,
                  c->d_scratch, c->img.real_elems, c->H, c->W);
     else if (c->slot_kind[fr] & 1)
@@ -1763,14 +1775,11 @@ int nik_dbg_polar(nik_ctx* c, const float* x, float* out) {
     float* d_out = reinterpret_cast<float*>(L.gbuf);
     float* d_in = c->d_scratch;
     HIP_TRY(c, hipMemcpyAsync(d_in, x, sizeof(float) * c->img.real_elems, hipMemcpyHostToDevice, s));
-    if (c->generic) {
-        g_shift_fix(s, 1, d_in, c->img.real_elems, L.splane, c->s_elems, c->H, c->W);
-        g_polar(s, 1, L.splane, c->s_elems, c->g_polar_map, d_out, c->pol.real_elems, c->H, c->PD, c->PC);
-    } else {
+    // (the shifted plane by the plain kernels -- any size --, the gather by the polar family's own kernel)
     launch_make_shifted(s, d_in, L.splane, c->H, c->W);
     launch_fix_zero(s, 1, L.splane, c->s_elems, c->H, c->W);
-    launch_A_fwd_polar(s, 1, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max, d_out);
-    }
+    if (c->gen_pol) g_polar(s, 1, L.splane, c->s_elems, c->g_polar_map, d_out, c->pol.real_elems, c->H, c->PD, c->PC);
+    else launch_A_fwd_polar(s, 1, c->pol.g, c->pol.t, L.splane, c->s_elems, c->H, c->W, c->polar, L.tmpA, c->spec_max, d_out);
     HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(float) * c->pol.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
     HIP_TRY(c, hipGetLastError());

@@ -16,13 +16,16 @@ from oracle import kcc_oracle as ko
 
 pytestmark = pytest.mark.gpu
 
+# fam: which plane families run the any-size kernels (nik_is_generic: bit 0 image, bit 1 polar) -- the choice is per family, so a
+# 640 x 480 camera with a 720 x 64 polar plane keeps the tiled image kernels
 GEOMS = [
-    pytest.param(dict(H=480, W=752, PD=720, PC=480), id="752x480"),          # EuRoC-style camera; 752 = 2^4 x 47
-    pytest.param(dict(H=512, W=512, PD=720, PC=480), id="512x512"),
-    pytest.param(dict(H=480, W=640, PD=720, PC=64), id="polar720x64"),        # config_geekplus.yaml's "64 may work well"
-    pytest.param(dict(H=480, W=640, PD=360, PC=240), id="polar360x240"),
-    pytest.param(dict(H=100, W=300, PD=120, PC=80), id="300x100-aspect3"),    # beyond 2:1: multi-period BORDER_WRAP
-    pytest.param(dict(H=62, W=94, PD=90, PC=50), id="94x62"),                 # nothing a multiple of 16; 94 = 2 x 47, 62 = 2 x 31
+    pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(1,)), id="752x480"),          # EuRoC-style camera; 752 = 2^4 x 47
+    pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(1,)), id="512x512"),
+    pytest.param(dict(H=480, W=640, PD=720, PC=64, fam=(2,)), id="polar720x64"),        # config_geekplus.yaml's "64 may work well"
+    pytest.param(dict(H=480, W=640, PD=360, PC=240, fam=(2,)), id="polar360x240"),
+    pytest.param(dict(H=448, W=448, PD=720, PC=64, fam=(2,)), id="448x448-polar720x64"),  # config_geekplus.yaml with that suggestion
+    pytest.param(dict(H=100, W=300, PD=120, PC=80, fam=(1, 3)), id="300x100-aspect3"),  # beyond 2:1: multi-period BORDER_WRAP
+    pytest.param(dict(H=62, W=94, PD=90, PC=50, fam=(3,)), id="94x62"),                 # nothing a multiple of 16; 94 = 2 x 47, 62 = 2 x 31
 ]
 
 
@@ -44,7 +47,7 @@ def test_any_size_geometry_matches_oracle(geom):
     H, W, PD, PC = geom["H"], geom["W"], geom["PD"], geom["PC"]
     n = 6
     N, cf, orc, ocfg = _mk(geom, n)
-    assert cf._L.nik_is_generic(cf._ctx) == 1
+    assert cf._L.nik_is_generic(cf._ctx) in geom["fam"]
     rng = np.random.default_rng(H + W)
     # FFT / IFFT of both plane families against the oracle's
     for which, (rows, cols) in enumerate([(H, W), (PD, PC)]):
@@ -87,8 +90,9 @@ def test_any_size_geometry_matches_oracle(geom):
 
 
 def test_any_size_family_agrees_with_the_tiled_kernels_at_640x480():
-    """where both families exist they must tell the same story: identical arg-max indices and poses on 32 pairs (up to the
-    rotation tie both are allowed against the oracle), PSR within 2e-3, spectra within float32 rounding"""
+    """where both families exist they must tell the same story -- also mixed (polar family on the any-size kernels, image family
+    tiled, and the other way round): identical arg-max indices and poses on 32 pairs (up to the rotation tie every one of them is
+    allowed against the oracle), PSR within 2e-3, spectra within float32 rounding"""
     import torch
     N = nik()
     H, W, PD, PC = FULL["H"], FULL["W"], FULL["PD"], FULL["PC"]
@@ -97,29 +101,34 @@ def test_any_size_family_agrees_with_the_tiled_kernels_at_640x480():
     dk, dc = torch.from_numpy(keys).cuda(), torch.from_numpy(curs).cuda()
     torch.cuda.synchronize()
     out = {}
-    for fam in ("tiled", "generic"):
-        if fam == "generic":
-            os.environ["NIK_GENERIC"] = "1"
+    forced = {"tiled": None, "generic": "1", "polar-generic": "2", "image-generic": "4"}      # $NIK_GENERIC: 1 both, bit 1 polar, bit 2 image
+    masks = {"tiled": 0, "generic": 3, "polar-generic": 2, "image-generic": 1}
+    for fam, env in forced.items():
+        if env:
+            os.environ["NIK_GENERIC"] = env
         try:
             cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=n, max_frames=2 * n)
         finally:
             os.environ.pop("NIK_GENERIC", None)
-        assert cf._L.nik_is_generic(cf._ctx) == (1 if fam == "generic" else 0)
+        assert cf._L.nik_is_generic(cf._ctx) == masks[fam]
         cf.intermedium_batch_dev(dk.data_ptr(), n, list(range(n)))
         res = [r.as_dict() for r in cf.track_batch_dev(dc.data_ptr(), list(range(n)), list(range(n, 2 * n)), True, sync=True)]
         _, f, p = cf.frame_export(n + 3)
         out[fam] = (res, f, p)
         cf.close()
-    (rt, ft, pt), (rg, fg, pg) = out["tiled"], out["generic"]
-    assert _relmax(fg, ft) < 3e-6 and _relmax(pg, pt) < 3e-5
+    rt, ft, pt = out["tiled"]
+    for fam in ("generic", "polar-generic", "image-generic"):
+        _, fg, pg = out[fam]
+        assert _relmax(fg, ft) < 3e-6 and _relmax(pg, pt) < 3e-5, fam
     ocfg = ko.default_config()
     poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, True, nthreads=min(32, os.cpu_count() or 1))
     for i in range(n):
-        for fam, r in (("tiled", rt[i]), ("generic", rg[i])):
+        for fam in forced:
+            r = out[fam][0][i]
             ok, _, msg = check_pose_parity(r, poses[i], infos[i], dbgs[i], PD)
             assert ok, "%s pair %d %s: %s" % (fam, i, motions[i], msg)
-        assert rg[i]["trans_row"] == rt[i]["trans_row"] and rg[i]["trans_col"] == rt[i]["trans_col"]
-        assert rg[i]["rot_col"] == rt[i]["rot_col"] and (rg[i]["rot_row"] - rt[i]["rot_row"]) % (PD // 2) == 0
+            assert r["trans_row"] == rt[i]["trans_row"] and r["trans_col"] == rt[i]["trans_col"], fam
+            assert r["rot_col"] == rt[i]["rot_col"] and (r["rot_row"] - rt[i]["rot_row"]) % (PD // 2) == 0, fam
 
 
 @pytest.mark.timeout(1800)
