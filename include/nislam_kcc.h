@@ -172,7 +172,8 @@ int nik_pose_batch_async(nik_ctx* ctx, int n, const nik_frame* keys, const nik_f
  * d_gray: n u8 images in HBM; keys[i]: slot holding pair i's keyframe spectra; cur_dst[i]: slot that
  * receives the current frame's image + spectra (so it can become a key later, map_builder.cc:99-106).
  * Asynchronous on nik_stream(); results land in `res` (host) after nik_synchronize(), or call with
- * sync=1 to block.  res may be pageable host memory. */
+ * sync=1 to block.  res may be pageable host memory; with sync=0 it is WRITTEN LATER (when a later call of the same
+ * stream retires this one, or at nik_synchronize): it must stay allocated until then. */
 int nik_track_batch_dev(nik_ctx* ctx, int n, const uint8_t* d_gray, const nik_frame* keys,
                         const nik_frame* cur_dst, int not_large_rotation, nik_pose_result* res, int sync);
 

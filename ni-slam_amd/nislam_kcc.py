@@ -457,6 +457,12 @@ class CorrelationFlow:
         n = len(keys)
         if res is None:
             res = (NikPoseResult * n)()
+        if not sync:
+            # an asynchronous call finalises its results into `res` when a later call of the lane retires it (or at synchronize()):
+            # the array must outlive the caller's interest in it -- keep the latest ones alive here
+            keep = self.__dict__.setdefault("_inflight", [])
+            keep.append(res)
+            del keep[:-16]
         self._chk(self._L.nik_track_batch_dev(self._ctx, n, C.c_void_p(int(d_gray_ptr)), _p(keys), _p(cur_dst),
                                               int(bool(not_large_rotation)), C.cast(res, C.c_void_p), int(bool(sync))))
         return res
