@@ -144,3 +144,44 @@ def test_callers_of_the_boundary_on_the_any_size_family():
                        cwd=root, env=env, capture_output=True, text=True, timeout=1700)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_random_even_geometries():
+    """a dozen random geometries -- even sizes from 12 to 180, whatever prime factors they have -- through ComputeIntermedium and both
+    ComputePose modes: the any-size kernels (and whichever tiled family happens to fit) against the oracle"""
+    N = nik()
+    rng = np.random.default_rng(20240)
+    done = 0
+    for trial in range(14):
+        H, W = (int(2 * rng.integers(6, 91)) for _ in range(2))
+        PD, PC = (int(2 * rng.integers(6, 81)) for _ in range(2))
+        cfg = N.default_config(rotation_divisor=PD, rotation_channel=PC)
+        ocfg = ko.default_config(rotation_divisor=PD, rotation_channel=PC)
+        try:
+            cf = N.CorrelationFlow(cfg, H, W, max_batch=2, max_frames=6)
+        except N.NikError as e:                      # (a polar map that leaves a very elongated image by more than one pixel is refused)
+            assert e.code == N.NIK_ERR_UNSUPPORTED_SIZE, str(e)
+            continue
+        orc = ko.Oracle(ocfg, H, W)
+        x = rng.random((W, H), dtype=np.float32)
+        assert _relmax(cf.dbg_fft(x, 0), orc.fft(x)) < 3e-6, (H, W)
+        assert np.array_equal(cf.dbg_polar(x), orc.polar(orc.fftshift(orc.remove_zero(x)))), (H, W, PD, PC)
+        keys, curs, motions = synth.make_batch(2, H, W, seed0=900 + trial, max_shift=max(1, min(H, W) // 10), max_theta=6.0)
+        for i in range(2):
+            cf.intermedium_u8(keys[i], i)
+            cf.intermedium_u8(curs[i], 2 + i)
+        assert np.array_equal(cf.dbg_rotate(2, -11), orc.rotate(orc.normalize_u8(curs[0]), -5.5)), (H, W)
+        for small in (True, False):
+            res = cf.pose_batch([0, 1], [2, 3], small)
+            poses, infos, dbgs, _ = ko.track_pairs(ocfg, keys, curs, small, nthreads=2)
+            for i in range(2):
+                def rerun(row, col, i=i):
+                    o = ko.Oracle(ocfg, H, W); o.force_rotation(row, col)
+                    kf, kp = o.intermedium(o.normalize_u8(keys[i])); ci = o.normalize_u8(curs[i]); _, cp = o.intermedium(ci)
+                    return o.compute_pose(kf, ci, kp, cp, small)
+                # tiny planes have shallow peaks (PSR ~ 10-30): the PSR tolerance of the full-size tests, the arg-max rule unchanged
+                ok, _, msg = check_pose_parity(res[i], poses[i], infos[i], dbgs[i], PD, psr_rtol=5e-3, rerun=rerun)
+                assert ok, "%dx%d polar %dx%d pair %d %s: %s" % (W, H, PD, PC, i, motions[i], msg)
+        cf.close()
+        done += 1
+    assert done >= 8
