@@ -84,7 +84,9 @@ static void stockham_pass(const ora_cf32* in, ora_cf32* out, int n, int r, int N
     const int m = n / r;
     const int tstep = n / (Ns * r);
     const int rstep = n / r;              /* W_r^t = tw[t*rstep] */
-    ora_cf32 v[64], y[64];
+    ora_cf32 vs[64], ys[64];
+    ora_cf32* v = vs; ora_cf32* y = ys;
+    if (r > 64) { v = (ora_cf32*)malloc(sizeof(ora_cf32) * 2 * (size_t)r); y = v + r; }   /* a prime factor beyond 61 (e.g. 158 = 2 x 79) */
     for (int j = 0; j < m; ++j) {
         const int k = j % Ns;
         for (int q = 0; q < r; ++q) {
@@ -120,6 +122,7 @@ static void stockham_pass(const ora_cf32* in, ora_cf32* out, int n, int r, int N
         const int j0 = (j / Ns) * Ns * r + k;
         for (int q = 0; q < r; ++q) out[j0 + q * Ns] = y[q];
     }
+    if (v != vs) free(v);
 }
 
 /* In-place unnormalised complex FFT of contiguous data[n]; work[n] scratch. */
