@@ -513,6 +513,8 @@ void nik_host_free(void* p);
 /* cv::warpAffine fixed-point terms of RotateArray(image, degree): out[2W+2H] = adelta | bdelta | X0 | Y0 */
 int nik_host_rot_terms(int H, int W, float degree, int* out);
 /* LDS box geometry of the u8 de-rotation for image height H: geom = {band_rows, bands, box_rows, pitch, lds_bytes} */
+/* radices (execution order, 0-terminated) of the run-time FFT plan the any-size kernels use for n points; returns their count */
+int  nik_host_fft_plan(int n, int radices[16]);
 int nik_host_rot8_geom(int H, int geom[5]);
 
 #ifdef __cplusplus

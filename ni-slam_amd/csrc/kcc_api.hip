@@ -122,7 +122,7 @@ struct nik_ctx {
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     // host frames -> device on the context's own upload stream (nik_upload_u8_async): never on a compute lane
-    hipStream_t up_stream = nullptr; hipEvent_t up_ev[4] = { nullptr, nullptr, nullptr, nullptr }; unsigned up_seq = 0;
+    hipStream_t up_stream = nullptr; hipEvent_t up_ev[4] = { nullptr, nullptr, nullptr, nullptr }; unsigned up_seq = 0; int up_fenced = -1;
     uint8_t* up_pin[2] = { nullptr, nullptr }; hipEvent_t up_pin_ev[2] = { nullptr, nullptr }; bool up_pin_busy[2] = { false, false };
     size_t up_pin_bytes = 0; int up_pin_next = 0;
     float* d_scratch = nullptr;          // debug / import-export staging
@@ -749,7 +749,11 @@ void lane_free(Lane& L) {
 // streams and work buffers of lanes [0, n): created on first use
 int ensure_lanes(nik_ctx* c, int n) {
     for (int li = 0; li < n && li < (int)c->lanes.size(); ++li)
-        if (!c->lanes[li].stream) { int rc = lane_alloc(c, c->lanes[li], (int)c->lanes.size()); if (rc) return rc; }
+        if (!c->lanes[li].stream) {
+            int rc = lane_alloc(c, c->lanes[li], (int)c->lanes.size());
+            if (rc) return rc;
+            if (c->up_fenced >= 0) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->up_ev[c->up_fenced & 3], 0));   // nik_upload_fence
+        }
     return NIK_OK;
 }
 
@@ -1085,9 +1089,11 @@ int nik_upload_u8_async(nik_ctx* c, int n, const uint8_t* gray, int stride, size
 int nik_upload_fence(nik_ctx* c, int ticket) {
     if (!c || ticket < 0 || !c->up_stream) return fail(c, NIK_ERR_INVALID_ARG, "no such upload");
     if ((unsigned)ticket + 4 < (c->up_seq & 0x3FFFFFFFu) ) return fail(c, NIK_ERR_INVALID_ARG, "upload ticket %d is older than the four tracked uploads", ticket);
-    int rc = ensure_lanes(c, c->active_lanes);
-    if (rc) return rc;
-    for (int li = 0; li < c->active_lanes; ++li) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->up_ev[ticket & 3], 0));
+    // (only the lanes that exist: a stream that is merely created takes a hardware queue from the ones that work; a lane created
+    // later waits for the latest fenced upload when it is created -- ensure_lanes)
+    for (int li = 0; li < c->active_lanes; ++li)
+        if (c->lanes[li].stream) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->up_ev[ticket & 3], 0));
+    c->up_fenced = ticket;
     return NIK_OK;
 }
 // device memory on the context's GPU for callers that do not link the HIP runtime themselves (the host-side tracker's upload ring)
@@ -1852,6 +1858,13 @@ int nik_host_rot_terms(int H, int W, float degree, int* out) {
     if (!out || H <= 0 || W <= 0) return NIK_ERR_INVALID_ARG;
     rotation_terms(H, W, degree, out);
     return NIK_OK;
+}
+// the run-time FFT plan the any-size kernels use for a line of n points: its radices in execution order (CPU tests)
+int nik_host_fft_plan(int n, int radices[16]) {
+    if (n < 1 || !radices) return NIK_ERR_INVALID_ARG;
+    const GPlan p = gplan_make(n, nullptr);
+    for (int i = 0; i < 16; ++i) radices[i] = i < p.nr ? p.radix[i] : 0;
+    return p.nr;
 }
 int nik_host_rot8_geom(int H, int geom[5]) {
     if (!geom || !fft_half_supported(H / 2)) return NIK_ERR_INVALID_ARG;

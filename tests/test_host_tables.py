@@ -221,3 +221,22 @@ def test_fft_butterflies_on_the_host(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-2000:]
     assert "pfa=1" in out.stdout and "pfa=0" in out.stdout
+
+
+def test_run_time_fft_plans_cover_every_even_length():
+    """the any-size kernels' plan of a line (nik_host_fft_plan, no GPU): for every even length the reference could hand over up to
+    8192 the radices multiply back to the length, the register butterflies {8, 4, 2, 3, 5, 7} come first and whatever is left is
+    prime (it runs as a direct DFT pass)"""
+    import ctypes as C
+    N = nik()
+    L = N.load()
+    L.nik_host_fft_plan.argtypes = [C.c_int, C.POINTER(C.c_int)]
+    r = (C.c_int * 16)()
+    def is_prime(v):
+        return v > 1 and all(v % d for d in range(2, int(v ** 0.5) + 1))
+    for n in list(range(4, 8193, 2)) + [47, 61, 79, 6561, 8191]:
+        k = L.nik_host_fft_plan(n, r)
+        rad = list(r[:k])
+        assert k >= 1 and int(np.prod(rad, dtype=np.int64)) == n, (n, rad)
+        assert all(x in (8, 4, 2, 3, 5, 7) or is_prime(x) for x in rad), (n, rad)
+    assert list(r[:L.nik_host_fft_plan(752, r)]) == [8, 2, 47] and list(r[:L.nik_host_fft_plan(480, r)]) == [8, 4, 3, 5]
