@@ -510,16 +510,18 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
     // ---- image family: fft_result, the zero-phase image, RemoveZeroComponent + fftshift -> the shifted plane S (:91-94)
     if (c->gen_img) {
         // any-size kernels (kcc_generic.hip): every stage its own launch, planes in the lane's work buffers
-        Stage st(c, L, "kg_intermedium_image", n * (double)I.real_elems);
         if (d_u8) {
-            g_u8_load(s, n, d_u8, I.real_elems, L.rbuf, RS, c->arena_u8, c->u8_stride, c->u8_pitch, dst, c->H, c->W);
+            { Stage st(c, L, "kg_u8_load", n * 5.0 * (double)I.real_elems);
+              g_u8_load(s, n, d_u8, I.real_elems, L.rbuf, RS, c->arena_u8, c->u8_stride, c->u8_pitch, dst, c->H, c->W); }
+            Stage st(c, L, "kg_rfft2<image>", n * (Rb(I) + 3 * Cb(I)));
             g_rfft2(s, n, c->gimg, L.rbuf, RS, c->H, nullptr, c->arena_F, I.spec_elems, dst);
         } else {
+            Stage st(c, L, "kg_rfft2<image>", n * (Rb(I) + 3 * Cb(I)));
             g_rfft2(s, n, c->gimg, c->arena_img, c->img_stride, c->img_pitch, dst, c->arena_F, I.spec_elems, dst);
         }
-        g_abs(s, n, c->arena_F, I.spec_elems, dst, L.gbuf, c->spec_max, I.spec_elems);
-        g_irfft2(s, n, c->gimg, L.gbuf, c->spec_max, nullptr, L.rbuf + c->r_elems, RS, c->H);
-        g_shift_fix(s, n, L.rbuf + c->r_elems, RS, L.splane, c->s_elems, c->H, c->W);
+        { Stage st(c, L, "kg_abs", n * 2 * Cb(I)); g_abs(s, n, c->arena_F, I.spec_elems, dst, L.gbuf, c->spec_max, I.spec_elems); }
+        { Stage st(c, L, "kg_irfft2<image>", n * (Rb(I) + 3 * Cb(I))); g_irfft2(s, n, c->gimg, L.gbuf, c->spec_max, nullptr, L.rbuf + c->r_elems, RS, c->H); }
+        { Stage st(c, L, "kg_shift_fix", n * 2 * Rb(I)); g_shift_fix(s, n, L.rbuf + c->r_elems, RS, L.splane, c->s_elems, c->H, c->W); }
     } else {
         if (d_u8) {
             const double N = (double)I.real_elems;
@@ -541,8 +543,8 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
     }
     // ---- polar family: polar(S) and its spectrum (:94)
     if (c->gen_pol) {
-        Stage st(c, L, "kg_intermedium_polar", n * (double)P.real_elems);
-        g_polar(s, n, L.splane, c->s_elems, c->g_polar_map, L.rbuf, RS, c->H, c->PD, c->PC);
+        { Stage st(c, L, "kg_polar", n * (Rb(I) + 2 * Rb(P))); g_polar(s, n, L.splane, c->s_elems, c->g_polar_map, L.rbuf, RS, c->H, c->PD, c->PC); }
+        Stage st(c, L, "kg_rfft2<polar>", n * (Rb(P) + 3 * Cb(P)));
         g_rfft2(s, n, c->gpol, L.rbuf, RS, c->PD, nullptr, c->arena_P, P.spec_elems, dst);
         return;
     }
@@ -563,15 +565,23 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
     if ((&f == &c->pol) ? c->gen_pol : c->gen_img) {
         // any-size family: Kzz and Kxz side by side as 2n planes (x_fwd never set: such contexts do not defer passes)
         const GFamily& gf = (&f == &c->pol) ? c->gpol : c->gimg;
-        Stage st(c, L, (&f == &c->pol) ? "kg_estimate_rot" : "kg_estimate_trans", 0.0);
+        const char* fam = (&f == &c->pol) ? "polar" : "image";
+        auto nm = [&](const char* k) { return std::string(k) + "<" + fam + ">"; };
         if (c->cfg.kernel == 1) launch_energy(s, n, f.g, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.energy);
-        g_mul(s, n, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, f.spec_elems, L.maxbuf);
-        g_irfft2(s, 2 * n, gf, L.kbuf, plane_stride, nullptr, L.rbuf, c->r_elems, f.g.rows);       // xz = IFFT(xzf)          (:212)
-        g_kernel(s, n, L.rbuf, c->r_elems, f.real_elems, kernel_fn(c), L.energy, L.maxbuf);        // kernel, max            (:213-214)
-        g_rfft2(s, 2 * n, gf, L.rbuf, c->r_elems, f.g.rows, nullptr, L.kbuf, plane_stride, nullptr);   // FFT(kernel)          (:215)
-        g_solve(s, n, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, f.g.cols, f.spec_elems);   // (:171-172)
-        g_irfft2(s, n, gf, L.gbuf, c->spec_max, nullptr, L.rbuf, 2 * c->r_elems, f.g.rows);        // g = IFFT(G)            (:173)
-        g_argmax(s, n, L.rbuf, 2 * c->r_elems, f.g.rows, f.g.cols, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror);
+        { Stage st(c, L, nm("kg_mul").c_str(), n * 4 * Cb(f));
+          g_mul(s, n, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, f.spec_elems, L.maxbuf); }
+        { Stage st(c, L, nm("kg_irfft2x2").c_str(), 2 * n * (Rb(f) + 3 * Cb(f)));
+          g_irfft2(s, 2 * n, gf, L.kbuf, plane_stride, nullptr, L.rbuf, c->r_elems, f.g.rows); }       // xz = IFFT(xzf)          (:212)
+        { Stage st(c, L, nm("kg_kernel").c_str(), 2 * n * 2 * Rb(f));
+          g_kernel(s, n, L.rbuf, c->r_elems, f.real_elems, kernel_fn(c), L.energy, L.maxbuf); }        // kernel, max            (:213-214)
+        { Stage st(c, L, nm("kg_rfft2x2").c_str(), 2 * n * (Rb(f) + 3 * Cb(f)));
+          g_rfft2(s, 2 * n, gf, L.rbuf, c->r_elems, f.g.rows, nullptr, L.kbuf, plane_stride, nullptr); }   // FFT(kernel)          (:215)
+        { Stage st(c, L, nm("kg_solve").c_str(), n * 3 * Cb(f));
+          g_solve(s, n, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, f.g.cols, f.spec_elems); }   // (:171-172)
+        { Stage st(c, L, nm("kg_irfft2").c_str(), n * (Rb(f) + 3 * Cb(f)));
+          g_irfft2(s, n, gf, L.gbuf, c->spec_max, nullptr, L.rbuf, 2 * c->r_elems, f.g.rows); }        // g = IFFT(G)            (:173)
+        { Stage st(c, L, nm("kg_argmax").c_str(), n * Rb(f));
+          g_argmax(s, n, L.rbuf, 2 * c->r_elems, f.g.rows, f.g.cols, L.partials, c->partial_stride, win.row, win.col, win.radius, win.mirror); }
         launch_finalize(s, n, L.partials, c->partial_stride, g_argmax_blocks(f.g.rows, f.g.cols), out, rot_index, n_hyp, c->PD, L.mirror);
         L.mirror = nullptr;
         return;
@@ -635,9 +645,11 @@ int enqueue_pose(nik_ctx* c, Lane& L, int n, int not_large_rotation, bool img_u8
     // FFT(RotateArray(image, -degree))  (:109 / :116-117): A pass with the rotation gather fused into its load
     if (c->gen_img) {
         // RotateArray + FFT, unfused: the rotated planes, then their spectra in tmpA
-        g_rotate(s, nt, img_u8 ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG),
-                 c->rot_tab, didx(L, IX_ROTIDX), L.rbuf, 2 * c->r_elems, c->H, c->W);
-        g_rfft2(s, nt, c->gimg, L.rbuf, 2 * c->r_elems, c->H, nullptr, L.tmpA, c->spec_max, nullptr);
+        { Stage st(c, L, "kg_rotate", nt * 2 * Rb(c->img));
+          g_rotate(s, nt, img_u8 ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG),
+                   c->rot_tab, didx(L, IX_ROTIDX), L.rbuf, 2 * c->r_elems, c->H, c->W); }
+        { Stage st(c, L, "kg_rfft2<rotated>", nt * (Rb(c->img) + 3 * Cb(c->img)));
+          g_rfft2(s, nt, c->gimg, L.rbuf, 2 * c->r_elems, c->H, nullptr, L.tmpA, c->spec_max, nullptr); }
         L.mirror = L.cur->h_trans;
         enqueue_estimate(c, L, nt, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems,
                          didx(L, IX_TKEY), L.trans_res, nullptr, 1, nullptr, 0, nullptr, wtr);

@@ -16,7 +16,7 @@ struct GFamily { PlaneGeom g; GPlan prow, pcol; };        // real plane rows x c
 
 enum { GF_C2C = 0, GF_R2C = 1, GF_C2R = 2 };
 struct GFArgs {
-    GPlan p; int mode, waves;
+    GPlan p; int mode, waves, tw_lds;
     const void* in; void* out;
     size_t in_item_stride, out_item_stride;              // elements (float on a real side, complex on a complex side)
     size_t in_line_stride, out_line_stride;

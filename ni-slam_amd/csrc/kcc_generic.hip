@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 #include "kcc_fft2.h"
 #include "kcc_pointwise.h"
@@ -30,7 +31,9 @@ GPlan gplan_make(int n, const float2* tw) {
     GPlan p{}; p.n = n; p.tw = reinterpret_cast<const gcf2*>(tw); p.nr = 0;
     int m = n;
     auto take = [&](int r) { while (m % r == 0 && p.nr < GPLAN_MAX_RADICES) { p.radix[p.nr++] = r; m /= r; } };
-    take(8); take(4); take(2); take(3); take(5); take(7);
+    // the largest in-register butterflies first (fewest passes: 720 = 16 x 15 x 3, 640 = 16 x 10 x 4, 480 = 16 x 15 x 2); the
+    // composite ones are the Good-Thomas / Cooley-Tukey compositions of kcc_fft2.h (dft_run)
+    take(16); take(15); take(12); take(10); take(9); take(8); take(7); take(6); take(5); take(4); take(3); take(2);
     for (int q = 11; q * q <= m; q += 2) take(q);            // whatever is left: odd primes, by direct DFT
     if (m > 1 && p.nr < GPLAN_MAX_RADICES) { p.radix[p.nr++] = m; m = 1; }
     if (m != 1) p.nr = 0;                                     // (cannot happen below 2^42)
@@ -53,10 +56,10 @@ __device__ __forceinline__ void g_pass(const cf2* __restrict__ in, cf2* __restri
 #pragma unroll
             for (int q = 1; q < R; ++q) { const cf2 w = tw[k * q * tstep]; v[q] = INV ? cmulc(v[q], w) : cmul(v[q], w); }
         }
-        Radix<R, INV>::run(v);
+        dft_run<R, INV>(v);                                   // output q sits in v[dft_pos<R>(q)] (identity for the base radices)
         const int j0 = (j - k) * R + k;
 #pragma unroll
-        for (int q = 0; q < R; ++q) out[j0 + q * Ns] = v[q];
+        for (int q = 0; q < R; ++q) out[j0 + q * Ns] = v[dft_pos<R>(q)];
     }
 }
 // any other (odd prime) radix p: a direct DFT, one output per lane and step
@@ -65,12 +68,17 @@ __device__ __forceinline__ void g_pass_prime(const cf2* __restrict__ in, cf2* __
     const int m = n / p, tstep = n / (Ns * p), pstep = n / p;
     for (int o = lane; o < n; o += 64) {
         const int j = o % m, qo = o / m, k = j % Ns;
+        // twiddle index of term q: (k q tstep + ((q qo) mod p) pstep) mod n, stepped without divisions (both parts stay < n)
+        const int dt = (k * tstep) % n, dq = qo * pstep;           // qo < p: dq < n
+        int t1 = 0, t2 = 0;
         cf2 acc = mk2(0.f, 0.f);
         for (int q = 0; q < p; ++q) {
             const cf2 x = in[j + q * m];
-            const int ti = (k * q * tstep + ((q * qo) % p) * pstep) % n;
+            int ti = t1 + t2; ti -= (ti >= n) ? n : 0;
             const cf2 w = tw[ti];
             acc = cadd(acc, INV ? cmulc(x, w) : cmul(x, w));
+            t1 += dt; t1 -= (t1 >= n) ? n : 0;
+            t2 += dq; t2 -= (t2 >= n) ? n : 0;
         }
         out[(j - k) * p + k + qo * Ns] = acc;
     }
@@ -90,6 +98,12 @@ __device__ __forceinline__ cf2* g_line(cf2* b0, cf2* b1, const GPlan& p, int lan
             case 5: g_pass<5, INV>(in, out, p.n, Ns, p.tw, lane); break;
             case 7: g_pass<7, INV>(in, out, p.n, Ns, p.tw, lane); break;
             case 8: g_pass<8, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 6: g_pass<6, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 9: g_pass<9, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 10: g_pass<10, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 12: g_pass<12, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 15: g_pass<15, INV>(in, out, p.n, Ns, p.tw, lane); break;
+            case 16: g_pass<16, INV>(in, out, p.n, Ns, p.tw, lane); break;
             default: g_pass_prime<INV>(in, out, p.n, r, Ns, p.tw, lane); break;
         }
         Ns *= r;
@@ -102,60 +116,104 @@ __device__ __forceinline__ cf2* g_line(cf2* b0, cf2* b1, const GPlan& p, int lan
 // ------------------------------------------------------------------------------------------------
 // line FFT kernel
 // ------------------------------------------------------------------------------------------------
+// A workgroup is `waves` wavefronts = `waves` ADJACENT lines.  The contiguous sides (real planes, spectrum rows) are loaded and
+// stored by each wavefront for its own line; the TRANSPOSED sides (the k-major spectrum seen from a column: element k of line c
+// sits at [k][c]) are loaded and stored by the whole workgroup, line index fastest, so that the `waves` columns of one spectrum
+// row are one contiguous piece (64 bytes at 8 lines) instead of 8-byte accesses a full row apart -- which was most of this
+// family's time (14.8 k -> see DESIGN 10 for the rate after).
 template <bool INV>
-__global__ __launch_bounds__(256) void kg_fft_lines(GFArgs a) {
+__global__ __launch_bounds__(512) void kg_fft_lines(GFArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int line = blockIdx.x * a.waves + wave, item = blockIdx.y;
-    if (line >= a.n_lines) return;                            // (whole wavefronts: no workgroup barrier in this kernel)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nthreads = blockDim.x;
+    const int line0 = blockIdx.x * a.waves, line = line0 + wave, item = blockIdx.y;
+    const bool active = line < a.n_lines;                     // (inactive wavefronts only keep the workgroup barriers company)
     const int n = a.p.n, h = n / 2;
-    cf2* b0 = reinterpret_cast<cf2*>(smem) + (size_t)wave * 2 * n;
+    // LDS: [the length's twiddle table, n entries -- when it fits the budget][two line buffers per wavefront].  The passes read one
+    // twiddle per point; with one butterfly per lane those are dependent loads with nothing to hide behind
+    cf2* const twl = reinterpret_cast<cf2*>(smem);
+    if (a.tw_lds) for (int i = threadIdx.x; i < n; i += nthreads) twl[i] = a.p.tw[i];
+    cf2* const base = twl + (a.tw_lds ? n : 0);
+    cf2* b0 = base + (size_t)wave * 2 * n;
     cf2* b1 = b0 + n;
-    const size_t iin = (size_t)(a.in_idx ? a.in_idx[item] : item) * a.in_item_stride + (size_t)line * a.in_line_stride;
-    const size_t iout = (size_t)(a.out_idx ? a.out_idx[item] : item) * a.out_item_stride + (size_t)line * a.out_line_stride;
+    GPlan plan = a.p; if (a.tw_lds) plan.tw = twl;
+    if (a.tw_lds) __syncthreads();
+    const size_t item_in = (size_t)(a.in_idx ? a.in_idx[item] : item) * a.in_item_stride;
+    const size_t item_out = (size_t)(a.out_idx ? a.out_idx[item] : item) * a.out_item_stride;
+    const size_t iin = item_in + (size_t)line * a.in_line_stride;
+    const size_t iout = item_out + (size_t)line * a.out_line_stride;
     if (a.mode == GF_R2C) {
-        const float* src = reinterpret_cast<const float*>(a.in) + iin;
-        for (int i = lane; i < n; i += 64) b0[i] = mk2(src[i], 0.f);
+        if (active) {
+            const float* src = reinterpret_cast<const float*>(a.in) + iin;
+            for (int i = lane; i < n; i += 64) b0[i] = mk2(src[i], 0.f);
+        }
     } else if (a.mode == GF_C2R) {
-        // half spectrum in: Hermitian completion; the imaginary parts of DC and Nyquist are ignored, as FFTW's c2r does
-        const cf2* src = reinterpret_cast<const cf2*>(a.in) + iin;
-        for (int k = lane; k <= h; k += 64) {
-            cf2 v = src[(size_t)k * a.in_elem_stride];
+        // half spectrum in (transposed side, cooperative): Hermitian completion; the imaginary parts of DC and Nyquist are
+        // ignored, as FFTW's c2r does
+        const cf2* src = reinterpret_cast<const cf2*>(a.in) + item_in + (size_t)line0 * a.in_line_stride;
+        const int nl = min(a.waves, a.n_lines - line0);
+        for (int idx = threadIdx.x; idx < (h + 1) * a.waves; idx += nthreads) {
+            const int k = idx / a.waves, w = idx - k * a.waves;
+            if (w >= nl) continue;
+            cf2 v = src[(size_t)k * a.in_elem_stride + (size_t)w * a.in_line_stride];
             if (k == 0 || k == h) v.y = 0.f;
-            b0[k] = v;
-            if (k != 0 && k != h) b0[n - k] = mk2(v.x, -v.y);
+            cf2* d = base + (size_t)w * 2 * n;
+            d[k] = v;
+            if (k != 0 && k != h) d[n - k] = mk2(v.x, -v.y);
+        }
+        __syncthreads();
+    } else {
+        if (active) {
+            const cf2* src = reinterpret_cast<const cf2*>(a.in) + iin;
+            for (int i = lane; i < n; i += 64) b0[i] = src[(size_t)i * a.in_elem_stride];
+        }
+    }
+    const cf2* r = b0;
+    if (active) r = g_line<INV>(b0, b1, plan, lane);
+    if (a.mode == GF_R2C) {
+        // (every line's result sits in the same one of its two buffers: the plan is the workgroup's)
+        const size_t roff = (size_t)((a.p.nr & 1) ? n : 0);
+        __syncthreads();
+        cf2* dst = reinterpret_cast<cf2*>(a.out) + item_out + (size_t)line0 * a.out_line_stride;
+        const int nl = min(a.waves, a.n_lines - line0);
+        for (int idx = threadIdx.x; idx < (h + 1) * a.waves; idx += nthreads) {
+            const int k = idx / a.waves, w = idx - k * a.waves;
+            if (w < nl) dst[(size_t)k * a.out_elem_stride + (size_t)w * a.out_line_stride] = base[(size_t)w * 2 * n + roff + k];
+        }
+    } else if (a.mode == GF_C2R) {
+        if (active) {
+            float* dst = reinterpret_cast<float*>(a.out) + iout;
+            for (int i = lane; i < n; i += 64) dst[i] = r[i].x * a.scale;
         }
     } else {
-        const cf2* src = reinterpret_cast<const cf2*>(a.in) + iin;
-        for (int i = lane; i < n; i += 64) b0[i] = src[(size_t)i * a.in_elem_stride];
-    }
-    const cf2* r = g_line<INV>(b0, b1, a.p, lane);
-    if (a.mode == GF_R2C) {
-        cf2* dst = reinterpret_cast<cf2*>(a.out) + iout;
-        for (int k = lane; k <= h; k += 64) dst[(size_t)k * a.out_elem_stride] = r[k];
-    } else if (a.mode == GF_C2R) {
-        float* dst = reinterpret_cast<float*>(a.out) + iout;
-        for (int i = lane; i < n; i += 64) dst[i] = r[i].x * a.scale;
-    } else {
-        cf2* dst = reinterpret_cast<cf2*>(a.out) + iout;
-        for (int i = lane; i < n; i += 64) dst[(size_t)i * a.out_elem_stride] = r[i];
+        if (active) {
+            cf2* dst = reinterpret_cast<cf2*>(a.out) + iout;
+            for (int i = lane; i < n; i += 64) dst[(size_t)i * a.out_elem_stride] = r[i];
+        }
     }
 }
 
 void launch_fft_lines(hipStream_t s, int n_items, GFArgs a, bool inv) {
     const int n = a.p.n;
-    // wavefronts (= lines) per workgroup: as many as 64 KB of LDS hold, at most 4; one for the longest lines
-    int waves = (int)std::min<size_t>(4, std::max<size_t>(1, (size_t)65536 / ((size_t)16 * n)));
+    // wavefronts (= adjacent lines) per workgroup: 8 where their line buffers fit 128 KB of LDS (transposed sides then move
+    // 64-byte pieces), else as many as fit; one for the longest lines
+    const size_t per_line = (size_t)2 * n * sizeof(cf2);
+    // ... but never so many that fewer than three workgroups fit a CU (the lines' loads and twiddle reads need other wavefronts
+    // to hide behind: 8 lines of 720 points per workgroup left one workgroup per CU and bought nothing)
+    const size_t tw_bytes = (size_t)n * sizeof(cf2);
+    static const int want_tw = getenv("NIK_G_TWLDS") ? atoi(getenv("NIK_G_TWLDS")) : 1;
+    a.tw_lds = (want_tw && tw_bytes + 2 * per_line <= (size_t)48 * 1024) ? 1 : 0;      // the table next to at least two lines
+    int waves = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)(48 * 1024) - (a.tw_lds ? tw_bytes : 0)) / per_line));
+    if (a.mode == GF_C2C) waves = std::min(waves, 4);        // (contiguous lines: nothing to gain from a wider workgroup)
     a.waves = waves;
-    const size_t lds = (size_t)waves * 2 * n * sizeof(cf2);
+    const size_t lds = (size_t)waves * per_line + (a.tw_lds ? tw_bytes : 0);
     dim3 grid((a.n_lines + waves - 1) / waves, n_items), block(64 * waves);
     if (inv) {
         static size_t cap = 65536;
-        if (lds > cap && hipFuncSetAttribute(reinterpret_cast<const void*>(&kg_fft_lines<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) cap = lds;
+        if (lds > cap && hipFuncSetAttribute(reinterpret_cast<const void*>(&kg_fft_lines<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) == hipSuccess) cap = 160 * 1024;
         hipLaunchKernelGGL(kg_fft_lines<true>, grid, block, lds, s, a);
     } else {
         static size_t cap = 65536;
-        if (lds > cap && hipFuncSetAttribute(reinterpret_cast<const void*>(&kg_fft_lines<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) cap = lds;
+        if (lds > cap && hipFuncSetAttribute(reinterpret_cast<const void*>(&kg_fft_lines<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)) == hipSuccess) cap = 160 * 1024;
         hipLaunchKernelGGL(kg_fft_lines<false>, grid, block, lds, s, a);
     }
 }
@@ -276,7 +334,7 @@ __global__ void kg_rotate(const uint8_t* __restrict__ arena_u8, size_t u8_stride
 __global__ void kg_mul(const cf2* __restrict__ X, size_t x_stride, const int* __restrict__ x_idx, const cf2* __restrict__ Z, size_t z_stride,
                        const int* __restrict__ z_idx, cf2* __restrict__ out, size_t item_stride, size_t plane_stride, size_t n, unsigned* __restrict__ maxbuf) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; const int item = blockIdx.y;
-    if (i == 0) { maxbuf[(size_t)(2 * item) * KCC_MAXPARTS] = 0u; maxbuf[(size_t)(2 * item + 1) * KCC_MAXPARTS] = 0u; }
+    for (size_t j = i; j < (size_t)2 * KCC_MAXPARTS; j += (size_t)gridDim.x * blockDim.x) maxbuf[(size_t)(2 * item) * KCC_MAXPARTS + j] = 0u;   // both planes' parts (contiguous)
     if (i >= n) return;
     const cf2 x = X[(size_t)(x_idx ? x_idx[item] : item) * x_stride + i], z = Z[(size_t)(z_idx ? z_idx[item] : item) * z_stride + i];
     cf2* o = out + (size_t)item * item_stride + i;
@@ -301,7 +359,19 @@ __global__ void kg_kernel(float* __restrict__ planes, size_t plane_stride, size_
         *p = k; mx = fabsf(k);
     }
     for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(maxbuf + (size_t)pl * KCC_MAXPARTS, __float_as_uint(mx));
+    // one part per wavefront, spread over the plane's KCC_MAXPARTS slots (thousands of wavefronts on ONE address serialised:
+    // this kernel ran at 0.8 TB/s); kg_maxfold folds the parts into slot 0 for kg_solve
+    if ((threadIdx.x & 63) == 0 && mx > 0.f) {
+        const unsigned slot = 1u + (unsigned)((blockIdx.x * 4u + (threadIdx.x >> 6)) % (unsigned)(KCC_MAXPARTS - 1));
+        atomicMax(maxbuf + (size_t)pl * KCC_MAXPARTS + slot, __float_as_uint(mx));
+    }
+}
+__global__ __launch_bounds__(64) void kg_maxfold(unsigned* __restrict__ maxbuf) {
+    unsigned* p = maxbuf + (size_t)blockIdx.x * KCC_MAXPARTS;
+    unsigned m = 0u;
+    for (int i = 1 + (int)threadIdx.x; i < KCC_MAXPARTS; i += 64) m = max(m, p[i]);
+    for (int off = 32; off >= 1; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if (threadIdx.x == 0) p[0] = m;
 }
 // H = T / (Kzz + lambda); G = H * Kxz   (correlation_flow.cc:171-172), T[k][l] = (-1)^(k+l); the arithmetic of kB<.,solve_inv>
 __global__ void kg_solve(const cf2* __restrict__ kk, size_t item_stride, size_t plane_stride, const unsigned* __restrict__ maxbuf, float lambda,
@@ -393,6 +463,7 @@ void g_kernel(hipStream_t s, int n_items, float* planes, size_t plane_stride, si
     if (fn.type == 1) hipLaunchKernelGGL(kg_kernel<KT_GAUSS>, grid1(elems, 2 * n_items), dim3(256), 0, s, planes, plane_stride, elems, fn, energy, size, maxbuf);
     else if (fn.power == 3) hipLaunchKernelGGL(kg_kernel<KT_POLY3>, grid1(elems, 2 * n_items), dim3(256), 0, s, planes, plane_stride, elems, fn, energy, size, maxbuf);
     else hipLaunchKernelGGL(kg_kernel<KT_POLYN>, grid1(elems, 2 * n_items), dim3(256), 0, s, planes, plane_stride, elems, fn, energy, size, maxbuf);
+    hipLaunchKernelGGL(kg_maxfold, dim3(2 * n_items), dim3(64), 0, s, maxbuf);
 }
 void g_solve(hipStream_t s, int n, const float2* kk, size_t item_stride, size_t plane_stride, const unsigned* maxbuf, float lambda, float2* G, size_t g_stride,
              int cols, size_t elems) {

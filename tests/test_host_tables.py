@@ -225,8 +225,8 @@ def test_fft_butterflies_on_the_host(tmp_path):
 
 def test_run_time_fft_plans_cover_every_even_length():
     """the any-size kernels' plan of a line (nik_host_fft_plan, no GPU): for every even length the reference could hand over up to
-    8192 the radices multiply back to the length, the register butterflies {8, 4, 2, 3, 5, 7} come first and whatever is left is
-    prime (it runs as a direct DFT pass)"""
+    8192 the radices multiply back to the length, the in-register butterflies (16, 15, 12, 10, 9, 8 ... 2) come first and whatever
+    is left is prime (it runs as a direct DFT pass)"""
     import ctypes as C
     N = nik()
     L = N.load()
@@ -238,5 +238,6 @@ def test_run_time_fft_plans_cover_every_even_length():
         k = L.nik_host_fft_plan(n, r)
         rad = list(r[:k])
         assert k >= 1 and int(np.prod(rad, dtype=np.int64)) == n, (n, rad)
-        assert all(x in (8, 4, 2, 3, 5, 7) or is_prime(x) for x in rad), (n, rad)
-    assert list(r[:L.nik_host_fft_plan(752, r)]) == [8, 2, 47] and list(r[:L.nik_host_fft_plan(480, r)]) == [8, 4, 3, 5]
+        assert all(x in (16, 15, 12, 10, 9, 8, 7, 6, 5, 4, 3, 2) or is_prime(x) for x in rad), (n, rad)
+    assert list(r[:L.nik_host_fft_plan(752, r)]) == [16, 47] and list(r[:L.nik_host_fft_plan(480, r)]) == [16, 15, 2]
+    assert list(r[:L.nik_host_fft_plan(720, r)]) == [16, 15, 3] and list(r[:L.nik_host_fft_plan(640, r)]) == [16, 10, 4]
