@@ -82,7 +82,7 @@ def _live_rocprof(args, workload, batch):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import rocprof_summary
         out = os.path.join(ROOT, "gpurun_out", "bench_live_prof")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "16", "--warmup", "6",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "40", "--warmup", "10",
                "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof"]
         r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=180)
         return r if r["stats"] else None
