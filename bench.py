@@ -83,7 +83,7 @@ def _live_rocprof(args, workload, batch):
         import rocprof_summary
         out = os.path.join(ROOT, "gpurun_out", "bench_live_prof")
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "40", "--warmup", "10",
-               "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof"]
+               "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof", "--repeats", "1"]
         r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=180)
         return r if r["stats"] else None
     except Exception as e:                                    # noqa: BLE001
