@@ -119,8 +119,7 @@ __device__ __forceinline__ cf2* g_line(cf2* b0, cf2* b1, const GPlan& p, int lan
 // A workgroup is `waves` wavefronts = `waves` ADJACENT lines.  The contiguous sides (real planes, spectrum rows) are loaded and
 // stored by each wavefront for its own line; the TRANSPOSED sides (the k-major spectrum seen from a column: element k of line c
 // sits at [k][c]) are loaded and stored by the whole workgroup, line index fastest, so that the `waves` columns of one spectrum
-// row are one contiguous piece (64 bytes at 8 lines) instead of 8-byte accesses a full row apart -- which was most of this
-// family's time (14.8 k -> see DESIGN 10 for the rate after).
+// row are one contiguous piece (64 bytes at 8 lines) instead of 8-byte accesses a full row apart.
 template <bool INV>
 __global__ __launch_bounds__(512) void kg_fft_lines(GFArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,11 +193,10 @@ __global__ __launch_bounds__(512) void kg_fft_lines(GFArgs a) {
 
 void launch_fft_lines(hipStream_t s, int n_items, GFArgs a, bool inv) {
     const int n = a.p.n;
-    // wavefronts (= adjacent lines) per workgroup: 8 where their line buffers fit 128 KB of LDS (transposed sides then move
-    // 64-byte pieces), else as many as fit; one for the longest lines
+    // wavefronts (= adjacent lines) per workgroup: up to 8 (the transposed sides then move 64-byte pieces), within 48 KB of LDS so
+    // that three workgroups fit a CU (a line is one wavefront's latency chain and needs the others to hide behind: 8 lines of 720
+    // points per workgroup left one workgroup per CU and bought nothing); one line for the longest lengths
     const size_t per_line = (size_t)2 * n * sizeof(cf2);
-    // ... but never so many that fewer than three workgroups fit a CU (the lines' loads and twiddle reads need other wavefronts
-    // to hide behind: 8 lines of 720 points per workgroup left one workgroup per CU and bought nothing)
     const size_t tw_bytes = (size_t)n * sizeof(cf2);
     static const int want_tw = getenv("NIK_G_TWLDS") ? atoi(getenv("NIK_G_TWLDS")) : 1;
     a.tw_lds = (want_tw && tw_bytes + 2 * per_line <= (size_t)48 * 1024) ? 1 : 0;      // the table next to at least two lines
