@@ -382,7 +382,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     win = min(args.batch, int(os.environ.get("NIK_SEQ_WINDOW", "64")))
     cfg = N.default_config()
 
-    def run(nframes, graphs=0):
+    def run(nframes, graphs=0, prefetch=True):
         flow = N.CorrelationFlow(cfg, H, W, max_batch=win, max_frames=nframes + win + 2, device=local_rank)
         flow.set_kzz_cache(True)
         flow.set_graphs(graphs)
@@ -392,6 +392,9 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
         outs = []
         for b0 in range(0, nframes, win):
             m = min(win, nframes - b0)
+            if prefetch and b0 + m < nframes:                   # the next window's spectra run beside this window's registrations
+                m2 = min(win, nframes - b0 - m)
+                trk.prefetch_dev(d_seq[b0 + m:b0 + m + m2].data_ptr(), m2)
             outs += trk.push_dev(d_seq[b0:b0 + m].data_ptr(), m)
         dt = time.perf_counter() - t1
         spec_box[:] = trk.speculation()

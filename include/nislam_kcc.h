@@ -236,11 +236,16 @@ void nik_tracker_destroy(nik_tracker* t);
  * keyframe in one batch and re-registered after every keyframe switch, so the outputs are exactly those of n
  * sequential calls.  n <= max_batch of the context. */
 int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out);
+/* ComputeIntermedium of the NEXT window started now (it does not depend on the key frame): it runs beside the current window's
+ * registrations; the nik_tracker_push_dev with the same pointer and n picks the spectra up (at most two windows under way).
+ * Outputs unchanged. */
+int  nik_tracker_prefetch_dev(nik_tracker* t, int n, const uint8_t* d_gray);
 /* one host frame (cv::Mat CV_8UC1) */
 int  nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out);
 /* n host frames (H rows of `stride` bytes each, `frame_stride` bytes apart): the reference's per-frame loop (main.cpp:51-86,
  * map_builder.cc:30-33) for a streamed caller.  Windows of max_batch frames; window k+1 is uploaded on the context's upload
- * stream while window k is registered.  Outputs are exactly those of n nik_tracker_push_u8 calls. */
+ * stream and window k+1's spectra are computed while window k is registered.  Outputs are exactly those of n
+ * nik_tracker_push_u8 calls. */
 int  nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride, size_t frame_stride, nik_track_output* out);
 /* number of keyframes inserted so far and their slots (for loop closure: nik_match over these) */
 int  nik_tracker_keyframes(const nik_tracker* t, nik_frame* slots, int cap, int* n);

@@ -78,7 +78,9 @@ struct nik_tracker {
     // (optimise when >= 2 have accumulated) and clears them (map_builder.cc:66-67,108-116)
     std::vector<nik_loop_result> loops;
     std::vector<nik_loop_result> all_loops;  // every loop ever found (diagnostics: nik_tracker_loops)
-    uint8_t* d_up[2] = { nullptr, nullptr }; // upload ring of nik_tracker_push_host: two windows of max_batch frames on the device
+    uint8_t* d_up[3] = { nullptr, nullptr, nullptr };   // upload ring of nik_tracker_push_host: three windows of max_batch frames on the device
+    struct Pre { const uint8_t* ptr; int n; std::vector<nik_frame> slots; };
+    std::vector<Pre> pre;                     // nik_tracker_prefetch_dev: windows whose spectra are under way (at most two)
     // Map::_edges (KCC edges between consecutive keyframes, loop edges) and the keyframes' robot poses
     struct EdgeRec { int from, to, type; double T[3]; };     // type 0 = KCC, 1 = Loop; T in camera units (edge->_T)
     std::vector<EdgeRec> edges;
@@ -345,9 +347,14 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     if (!t || !d_gray || !out || n < 0) return NIK_ERR_INVALID_ARG;
     if (n == 0) return NIK_OK;
     if (n > t->max_batch) return NIK_ERR_CAPACITY;
-    if ((int)t->free_slots.size() < n) return NIK_ERR_CAPACITY;
+    // a window whose spectra were started by nik_tracker_prefetch_dev (same pointer, same n) owns its slots already
+    int pi = -1;
+    for (size_t q = 0; q < t->pre.size(); ++q) if (t->pre[q].ptr == d_gray && t->pre[q].n == n) { pi = (int)q; break; }
+    const bool pre = pi >= 0;
+    if (!pre && (int)t->free_slots.size() < n) return NIK_ERR_CAPACITY;
     std::vector<nik_frame> slot(n);
-    for (int i = 0; i < n; ++i) { slot[i] = t->free_slots.back(); t->free_slots.pop_back(); }
+    if (pre) { slot = t->pre[pi].slots; t->pre.erase(t->pre.begin() + pi); }
+    else for (int i = 0; i < n; ++i) { slot[i] = t->free_slots.back(); t->free_slots.pop_back(); }
     std::vector<nik_pose_result> res(t->max_batch);          // (a batch may hold a frame more than once: once per key segment)
     std::vector<nik_frame> keys(t->max_batch);
     int rc, start = 0;
@@ -355,7 +362,7 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     // on an error: frames that did not become keyframes give their slots back; outputs of unprocessed frames stay zero
     auto bail = [&](int code) { for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]); return code; };
     // the spectra of a frame do not depend on the keyframe: all n frames in one batch
-    if ((rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return bail(rc);
+    if (!pre && (rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return bail(rc);
     if (!t->init) { first_frame(t, slot[0], out[0]); start = 1; }
     struct Seg { int key_idx, first, count, res_off; };             // key_idx: index into this push (-1: the current keyframe)
     std::vector<Seg> segs;
@@ -451,29 +458,49 @@ int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_tra
     return t->map_rc;
 }
 
+// ComputeIntermedium of the NEXT window, started now: the spectra of a frame do not depend on the key frame (map_builder.cc:33 runs
+// ComputeFFTResult before anything else), so a streamed caller starts them for window k+1 before it pushes window k -- they
+// run beside window k's registrations and their host round trips.  A later nik_tracker_push_dev with the same pointer and n
+// picks them up (at most two windows may be under way); outputs are unchanged.
+int nik_tracker_prefetch_dev(nik_tracker* t, int n, const uint8_t* d_gray) {
+    if (!t || !d_gray || n <= 0 || t->pre.size() >= 2) return NIK_ERR_INVALID_ARG;
+    if (n > t->max_batch || (int)t->free_slots.size() < n) return NIK_ERR_CAPACITY;
+    nik_tracker::Pre P{ d_gray, n, std::vector<nik_frame>(n) };
+    for (int i = 0; i < n; ++i) { P.slots[i] = t->free_slots.back(); t->free_slots.pop_back(); }
+    const int rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, P.slots.data());
+    if (rc) { for (int i = n - 1; i >= 0; --i) t->free_slots.push_back(P.slots[i]); return rc; }
+    t->pre.push_back(std::move(P));
+    return NIK_OK;
+}
+
 // n host frames (cv::Mat CV_8UC1 each: H rows of `stride` bytes, `frame_stride` bytes apart) -- the reference's per-frame loop
-// (main.cpp:51-86: GetImage -> AddNewInput) for a streamed caller.  The frames travel in windows of max_batch: window k+1 is
-// uploaded on the context's upload stream (nik_upload_u8_async: pinned sources by DMA, pageable ones through pinned staging)
-// while window k is registered, so the PCIe transfer hides behind the registration; outputs are those of n push_u8 calls.
+// (main.cpp:51-86: GetImage -> AddNewInput) for a streamed caller.  The frames travel in windows of max_batch: while window k is
+// registered, window k+1's spectra are computed (nik_tracker_prefetch_dev) and window k+2 is uploaded on the context's upload
+// stream (nik_upload_u8_async: pinned sources by DMA, pageable ones through pinned staging), so neither the PCIe transfer nor
+// ComputeIntermedium waits for the registrations' host round trips; outputs are those of n push_u8 calls.
 int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride, size_t frame_stride, nik_track_output* out) {
-    if (!t || !gray || !out || n < 0) return NIK_ERR_INVALID_ARG;
+    if (!t || !gray || !out || n < 0 || !t->pre.empty()) return NIK_ERR_INVALID_ARG;
     if (n == 0) return NIK_OK;
     const size_t fb = (size_t)t->H * t->W;
-    const int win = t->max_batch;
+    const int win = t->max_batch, nw = (n + win - 1) / win;
     int rc;
     for (uint8_t*& p : t->d_up)
         if (!p) { void* q = nullptr; if ((rc = nik_dev_malloc(t->ctx, fb * win, &q))) return rc; p = (uint8_t*)q; }
-    int tk = nik_upload_u8_async(t->ctx, std::min(win, n), gray, stride, frame_stride, t->d_up[0]);
-    if (tk < 0) return tk;
-    for (int b = 0, j = 0; b < n; b += win, ++j) {
-        const int m = std::min(win, n - b);
-        if ((rc = nik_upload_fence(t->ctx, tk))) return rc;   // this window's registration waits for ITS upload only
-        if (b + m < n) {
-            // (the other buffer's previous window was consumed by a push_dev that has returned: free to overwrite)
-            tk = nik_upload_u8_async(t->ctx, std::min(win, n - b - m), gray + (size_t)(b + m) * frame_stride, stride, frame_stride, t->d_up[(j + 1) & 1]);
-            if (tk < 0) return tk;
+    auto count = [&](int k) { return std::min(win, n - k * win); };
+    auto upload = [&](int k) { return nik_upload_u8_async(t->ctx, count(k), gray + (size_t)k * win * frame_stride, stride, frame_stride, t->d_up[k % 3]); };
+    std::vector<int> tk(nw + 2, -1);
+    if ((tk[0] = upload(0)) < 0) return tk[0];
+    if (nw > 1 && (tk[1] = upload(1)) < 0) return tk[1];
+    if ((rc = nik_upload_fence(t->ctx, tk[0]))) return rc;
+    for (int k = 0; k < nw; ++k) {
+        if (k + 1 < nw) {
+            // window k+1: its upload was enqueued a whole window ago -- wait for it on the device, start its spectra; window k+2:
+            // start its upload (into the buffer of window k-1, whose push has returned)
+            if ((rc = nik_upload_fence(t->ctx, tk[k + 1]))) return rc;
+            if (k + 2 < nw && (tk[k + 2] = upload(k + 2)) < 0) return tk[k + 2];
+            if ((rc = nik_tracker_prefetch_dev(t, count(k + 1), t->d_up[(k + 1) % 3]))) return rc;
         }
-        if ((rc = nik_tracker_push_dev(t, m, t->d_up[j & 1], out + b))) return rc;
+        if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return rc;
     }
     return nik_upload_wait(t->ctx);
 }

@@ -229,6 +229,15 @@ def test_push_host_equals_push_dev():
         want += trk.push_dev(d[b:b + window].data_ptr(), min(window, n - b))
     trk.close(); flow.close()
     assert sum(o["inserted"] for o in want) >= 4
+    # the next window's spectra started before the current window is pushed (nik_tracker_prefetch_dev): same outputs
+    flow, trk = fresh(window)
+    got_prefetch = []
+    for b in range(0, n, window):
+        m = min(window, n - b)
+        if b + m < n:
+            trk.prefetch_dev(d[b + m:b + m + window].data_ptr(), min(window, n - b - m))
+        got_prefetch += trk.push_dev(d[b:b + m].data_ptr(), m)
+    trk.close(); flow.close()
     flow, trk = fresh(window)
     got_pageable = trk.push_host(frames)
     trk.close(); flow.close()
@@ -247,7 +256,7 @@ def test_push_host_equals_push_dev():
     flow, trk = fresh(1)
     got_single = [trk.push_u8(f) for f in frames[:24]]
     trk.close(); flow.close()
-    for name, got in (("pageable", got_pageable), ("pinned", got_pinned), ("padded", got_padded), ("push_u8", got_single)):
+    for name, got in (("prefetch", got_prefetch), ("pageable", got_pageable), ("pinned", got_pinned), ("padded", got_padded), ("push_u8", got_single)):
         for a, b in zip(got, want):
             for k in keys:
                 assert a[k] == b[k], (name, a["frame_id"], k, a[k], b[k])
