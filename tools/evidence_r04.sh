@@ -16,7 +16,7 @@ python tools/parity_sweep.py 256 10.0 0 480 752 > $O/r04_parity_sweep_752x480_ge
 NIK_GENERIC=1 python tools/parity_sweep.py 512 10.0 0 > $O/r04_parity_sweep_generic_640x480.json 2> $O/r04_parity_sweep_generic.err
 NIK_GENERIC=1 python bench.py --no-live-prof --no-profile --cpu-sample 16 --no-cached --repeats 3 > $O/r04_generic_family_bench.json 2>/dev/null
 bash tools/pmc_sq.sh > $O/r04_pmc_sq.log 2>&1
-python tools/pmc_sq_table.py > $O/r04_pmc_sq_table.txt 2>&1
+python tools/pmc_sq_table.py $O/pmcsq $O/r04_kernel_times.json > $O/r04_pmc_sq_table.csv 2>/dev/null
 for f in r04_workload_sequence r04_workload_pyramid r04_workload_loop4096 r04_workload_hd r04_generic_family_bench; do python -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', d['value'], d['path_roofline']['frac_of_8TBps'], d.get('parity_spot_check'), d.get('host_inclusive'))"; done
 head -c 600 $O/r04_parity_sweep.json; echo; head -c 600 $O/r04_parity_sweep_752x480_generic.json; echo; head -c 400 $O/r04_parity_sweep_generic_640x480.json; echo
