@@ -1813,7 +1813,6 @@ int nik_dbg_response(nik_ctx* c, int which, nik_frame key, nik_frame cur, int de
     if (!c || !g || (which != 0 && which != 1)) return NIK_ERR_INVALID_ARG;
     int rc;
     if ((rc = check_kernel(c)) || (rc = nik_synchronize(c)) || (rc = check_slot(c, key, true)) || (rc = check_slot(c, cur, true))) return rc;
-    if (c->generic) return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "nik_dbg_response is a tap of the tiled kernels (this context runs the any-size family)");
     if (c->kzz_cache && (rc = ensure_kzz(c, 1, &key))) return rc;
     Lane& L = c->lanes[0]; hipStream_t s = L.stream;
     if ((rc = begin_call(c, L)) || (rc = depend_on_slot(c, L, 0, key)) || (rc = depend_on_slot(c, L, 0, cur))) return rc;
@@ -1829,11 +1828,18 @@ int nik_dbg_response(nik_ctx* c, int which, nik_frame key, nik_frame cur, int de
         HIP_TRY(c, hipMemcpyAsync(c->rot_one, terms.data(), sizeof(int) * terms.size(), hipMemcpyHostToDevice, s));
         HIP_TRY(c, hipMemsetAsync(didx(L, IX_ROTIDX), 0, sizeof(int), s));
         if (!(c->slot_kind[cur] & 1) && (rc = ensure_f32_images(c, L, 0, 1, &cur))) return rc;
-        if (c->slot_kind[cur] & 1)
+        if (c->gen_img) {
+            g_rotate(s, 1, (c->slot_kind[cur] & 1) ? c->arena_u8 : nullptr, c->u8_stride, c->u8_pitch, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG),
+                     c->rot_one, didx(L, IX_ROTIDX), L.rbuf, 2 * c->r_elems, c->H, c->W);
+            g_rfft2(s, 1, c->gimg, L.rbuf, 2 * c->r_elems, c->H, nullptr, L.tmpA, c->spec_max, nullptr);
+            enqueue_estimate(c, L, 1, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems, didx(L, IX_TKEY), L.trans_res, nullptr, 1);
+        } else if (c->slot_kind[cur] & 1)
             launch_A_fwd_rot8(s, 1, c->img.g, c->img.t, c->arena_u8, c->u8_stride, c->u8_pitch, didx(L, IX_TIMG), c->rot_one, didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
         else
             launch_A_fwd_rot(s, 1, c->img.g, c->img.t, c->arena_img, c->img_stride, c->img_pitch, didx(L, IX_TIMG), c->rot_one, didx(L, IX_ROTIDX), L.tmpA, c->spec_max);
-        if (c->cfg.kernel == 1) {
+        if (c->gen_img) {
+            // (done above)
+        } else if (c->cfg.kernel == 1) {
             launch_B_fwd(s, 1, c->img.g, c->img.t, L.tmpA, c->spec_max, L.tmpA, c->spec_max, nullptr);
             enqueue_estimate(c, L, 1, c->img, false, L.tmpA, c->spec_max, nullptr, c->arena_F, c->img.spec_elems, didx(L, IX_TKEY), L.trans_res, nullptr, 1);
         } else {
@@ -1841,7 +1847,8 @@ int nik_dbg_response(nik_ctx* c, int which, nik_frame key, nik_frame cur, int de
         }
     }
     float* d_g = reinterpret_cast<float*>(L.kbuf);            // (the kernel planes are consumed by now)
-    launch_A_inv_real(s, 1, f.g, f.t, L.gbuf, c->spec_max, d_g, f.real_elems);
+    if (which ? c->gen_img : c->gen_pol) d_g = L.rbuf;        // the any-size kernels materialise g (item 0, plane 0) before their arg-max
+    else launch_A_inv_real(s, 1, f.g, f.t, L.gbuf, c->spec_max, d_g, f.real_elems);
     HIP_TRY(c, hipMemcpyAsync(g, d_g, sizeof(float) * f.real_elems, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipGetLastError());
     L.cur->has_pose = false;
