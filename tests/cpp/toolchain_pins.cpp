@@ -5,6 +5,7 @@
 //      the oracle evaluates (float)pow((double)x, (double)p), the HIP kernels (float)((double)x * x * x) for p = 3.
 //   2. complex<float> division (correlation_flow.cc:171, T / (Kzz + lambda)): libstdc++'s operator/ against the textbook formula
 //      the oracle and the HIP ridge solve use, ((ac + bd) / |z|^2, (bc - ad) / |z|^2).
+//   3. fft_result.abs() (correlation_flow.cc:92): std::abs(complex<float>) against sqrtf(re^2 + im^2).
 #include <cmath>
 #include <complex>
 #include <cstdint>
@@ -52,7 +53,18 @@ int main() {
         const float small = std::fabs(re) > std::fabs(im) ? std::fabs(im) : std::fabs(re);
         if (small > 1e-3f * big) { ++n_div; differ += u != 0; if (u > worst) worst = u; }
     }
-    printf("{\"pow_samples\": %ld, \"libpow_ne_oracle\": %ld, \"libpow_ne_double_cube\": %ld, \"libpow_ne_float_cube\": %ld, "
+    // 3. |F| (correlation_flow.cc:92, fft_result.abs()): std::abs(complex<float>) (hypot) against sqrtf(re^2 + im^2), what the oracle
+    //    and the HIP kernel evaluate
+    long n_abs = 0, abs_differ = 0; int abs_worst = 0;
+    for (int i = 0; i < 6000000; ++i) {
+        const float mag = std::exp(unit() * 16.0f - 4.0f), ph = unit() * 6.2831853f;
+        const std::complex<float> z(mag * std::cos(ph), mag * std::sin(ph));
+        const float lib = std::abs(z), mine = sqrtf(z.real() * z.real() + z.imag() * z.imag());
+        const int u = ulps(lib, mine);
+        ++n_abs; abs_differ += u != 0; if (u > abs_worst) abs_worst = u;
+    }
+    printf("{\"abs_samples\": %ld, \"abs_differ\": %ld, \"abs_worst_ulps\": %d, ", n_abs, abs_differ, abs_worst);
+    printf("\"pow_samples\": %ld, \"libpow_ne_oracle\": %ld, \"libpow_ne_double_cube\": %ld, \"libpow_ne_float_cube\": %ld, "
            "\"div_samples\": %ld, \"div_differ\": %ld, \"div_worst_ulps\": %d}\n",
            n_pow, pow_vs_oracle, pow_vs_cube, float_cube_differs, n_div, differ, worst);
     return 0;

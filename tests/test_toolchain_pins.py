@@ -26,3 +26,6 @@ def test_libstdcxx_pow_and_complex_division(tmp_path):
     # magnitude below the measured float32 conditioning of T / (Kzz + lambda) (6e-4 of the peak), which the parity rule
     # already carries
     assert d["div_samples"] >= 5000000 and d["div_worst_ulps"] <= 2
+    # fft_result.abs() (correlation_flow.cc:92): std::abs(complex<float>) (hypot) against sqrtf(re^2 + im^2): 15 % of the samples
+    # differ, never by more than 1 ulp
+    assert d["abs_samples"] >= 5000000 and d["abs_worst_ulps"] <= 1
