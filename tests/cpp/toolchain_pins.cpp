@@ -26,6 +26,11 @@ static inline int ulps(float a, float b) {
 
 int main() {
     static_assert(std::is_same<decltype(std::pow(1.0f, 3)), double>::value, "std::pow(float, int) must return double (C++11 promotion)");
+    // 0. cvRound (RECALLED row 6: lrint / cvtsd2si under the default rounding mode) rounds halves to even -- what the oracle's
+    //    and the host tables' lrint / lrintf do in this libc
+    if (lrint(0.5) != 0 || lrint(1.5) != 2 || lrint(2.5) != 2 || lrint(-0.5) != 0 || lrint(-1.5) != -2 || lrintf(3.5f) != 4 || lrintf(4.5f) != 4) {
+        printf("{\"lrint_half_even\": false}\n"); return 1;
+    }
     // 1. cubes over the range of (xz + offset): correlation values from ~1e-1 to ~1e5, both signs
     long n_pow = 0, pow_vs_oracle = 0, pow_vs_cube = 0, float_cube_differs = 0;
     for (int i = 0; i < 6000000; ++i) {
