@@ -23,6 +23,7 @@
 #ifndef NISLAM_KCC_H
 #define NISLAM_KCC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -166,6 +167,14 @@ int nik_pose_batch(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* 
 /* the same without waiting: res is final after nik_synchronize (or once as many further calls as the call depth -- 2 by default, nik_set_call_depth -- have been enqueued on every stream) */
 int nik_pose_batch_async(nik_ctx* ctx, int n, const nik_frame* keys, const nik_frame* curs,
                          int not_large_rotation, nik_pose_result* res);
+/* the results of ONE asynchronous batch: returns when every in-flight call that writes into res[0, n) has finished and its
+ * results are final (calls of a stream retire in order, so whatever that stream was given earlier is finished too); calls
+ * enqueued later keep running.  With it a caller keeps several batches in flight and consumes them in order (kcc_tracker.cpp's
+ * look-ahead batches) instead of draining the context with nik_synchronize. */
+int nik_wait_results(nik_ctx* ctx, const nik_pose_result* res, int n);
+/* on: successive batched calls start on successive streams of the context (by default every call starts on the first one, so
+ * small calls queue behind each other); outputs are unchanged.  Set by nik_tracker_create for its context. */
+int nik_set_lane_rotation(nik_ctx* ctx, int on);
 
 /* The benchmark unit of SURVEY.md 8(d): for each of n pairs,
  *   ComputeIntermedium(current image) + ComputePose(key, current, not_large_rotation).

@@ -133,6 +133,7 @@ struct nik_ctx {
     int last_pose_n = -1, last_pose_nhyp = 0, last_pose_nc = 0;   // shape of the latest pose call (nik_pose_batch_chained checks it)
     hipStream_t stats_stream = nullptr; hipEvent_t stats_done = nullptr; bool stats_pending = false;
     int graph_max = 0;                   // batches of <= graph_max pairs replay a captured hipGraph (0: off); $NIK_GRAPH
+    bool lane_rot = false; int lane_base = 0;   // nik_set_lane_rotation: successive calls start on successive lanes (several small calls in flight run side by side)
     hipEvent_t fence_ev = nullptr;       // nik_wait_for
     hipEvent_t chain_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // a finer pyramid level has read lane li's surface results
     bool chain_pending[4] = { false, false, false, false };
@@ -1016,10 +1017,14 @@ int nik_intermedium_batch_dev(nik_ctx* c, int n, const uint8_t* d_gray, const ni
     int rc;
     for (int i = 0; i < n; ++i) if ((rc = check_slot(c, dst[i], false))) return rc;
     const int nl = lanes_for(c, n);
-    if ((rc = ensure_lanes(c, nl))) return rc;
-    for (int li = 0; li < nl; ++li) {
-        int b, e; chunk_of(n, nl, li, b, e);
+    const bool rot = c->lane_rot && c->active_lanes > 1;
+    const int LN = rot ? c->active_lanes : nl, base = rot ? c->lane_base : 0;
+    if ((rc = ensure_lanes(c, LN))) return rc;
+    if (rot) c->lane_base = (base + nl) % LN;
+    for (int ci = 0; ci < nl; ++ci) {
+        int b, e; chunk_of(n, nl, ci, b, e);
         const int m = e - b; if (m <= 0) continue;
+        const int li = (base + ci) % LN;
         Lane& L = c->lanes[li];
         if ((rc = begin_call(c, L))) return rc;
         for (int i = 0; i < m; ++i) { if ((rc = depend_for_write(c, L, li, dst[b + i]))) return rc; hidx(L, IX_DST)[i] = dst[b + i]; }
@@ -1257,7 +1262,12 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     int rc;
     if (c->kzz_cache && (rc = ensure_kzz(c, n, keys))) return rc;
     const int nl = lanes_for(c, n);
-    if ((rc = ensure_lanes(c, nl))) return rc;
+    // lane rotation (nik_set_lane_rotation): the call's chunks go to the lanes behind those of the previous call, so that several
+    // calls in flight -- a tracker's look-ahead batches -- run side by side instead of queueing on lane 0
+    const bool rot = c->lane_rot && !upper && c->active_lanes > 1;
+    const int LN = rot ? c->active_lanes : nl, lane_base = rot ? c->lane_base : 0;
+    if ((rc = ensure_lanes(c, LN))) return rc;
+    if (rot) c->lane_base = (lane_base + nl) % LN;
     // chunks: one per lane, or -- $NIK_CHUNK / nik_set_chunk -- pieces of at most chunk_pairs pairs dealt to the lanes in turn.
     // Small chunks keep a kernel's output in the 256 MiB Infinity Cache until the next kernel of the lane reads it.
     int nc = nl;
@@ -1272,7 +1282,7 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
     if (c->want_stats && c->stats_parts + nc > KCC_STATS_PARTS) return fail(c, NIK_ERR_CAPACITY, "residual statistics: more than %d chunks in one call", (int)KCC_STATS_PARTS);
     c->last_pose_n = n; c->last_pose_nhyp = not_large_rotation ? 1 : 2; c->last_pose_nc = nc;
     for (int ci = 0; ci < nc; ++ci) {
-        const int li = ci % nl;
+        const int li = (lane_base + ci % nl) % LN;
         int b, e; chunk_of(n, nc, ci, b, e);
         const int m = e - b; if (m <= 0) continue;
         Lane& L = c->lanes[li];
@@ -1393,6 +1403,31 @@ int nik_pose_batch(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* cu
     int rc = nik_pose_batch_async(c, n, keys, curs, not_large_rotation, res);
     if (rc || n <= 0) return rc;
     return drain_all(c);
+}
+
+// Results of one asynchronous batch: waits for (and finalises) every in-flight call that writes into res[0, n), and -- calls of a
+// lane retire in order -- whatever that lane was given before them.  Later calls keep running.
+int nik_wait_results(nik_ctx* c, const nik_pose_result* res, int n) {
+    if (!c || !res || n < 0) return fail(c, NIK_ERR_INVALID_ARG, "null/negative argument");
+    for (int li = 0; li < c->active_lanes; ++li) {
+        Lane& L = c->lanes[li];
+        int last = -1;
+        for (int k = 0; k < L.ring_n; ++k) {        // oldest call first
+            const Call& call = L.ring[(L.next + k) % L.ring_n];
+            if (call.busy && call.res && call.res >= res && call.res < res + n) last = k;
+        }
+        for (int k = 0; k <= last; ++k) {
+            int rc = retire(c, L.ring[(L.next + k) % L.ring_n]);
+            if (rc) return rc;
+        }
+    }
+    return NIK_OK;
+}
+
+int nik_set_lane_rotation(nik_ctx* c, int on) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    c->lane_rot = on != 0;
+    return NIK_OK;
 }
 
 int nik_pose_batch_window(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, const int32_t* centers, int radius,

@@ -6,7 +6,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 namespace {
@@ -81,6 +83,85 @@ struct nik_tracker {
     uint8_t* d_up[3] = { nullptr, nullptr, nullptr };   // upload ring of nik_tracker_push_host: three windows of max_batch frames on the device
     struct Pre { const uint8_t* ptr; int n; std::vector<nik_frame> slots; };
     std::vector<Pre> pre;                     // nik_tracker_prefetch_dev: windows whose spectra are under way (at most two)
+    // ---- look-ahead batches (nik_tracker_push_dev) ----
+    // Frames are named by their frame id (gid: the id apply_result will give them -- frames are consumed in order, so the id of
+    // every known frame is fixed the moment it is handed over).  A Flight is one asynchronous nik_pose_batch_async call: a cache
+    // of ComputePose results for (key frame, current frame) pairs, planned from the tracker's GUESS of the coming key frames.  A
+    // result is used iff its key is the frame the reference's rule really made the key frame and its slots are the frames'
+    // slots -- so the outputs are those of frame-by-frame calls whatever was guessed; a wrong guess only wastes its GPU work.
+    struct Seg { int key_gid; nik_frame key_slot; int first_gid, count, res_off; };
+    struct Flight {
+        std::vector<Seg> segs; std::vector<nik_frame> keys, curs; std::vector<nik_pose_result> res;
+        int total = 0; bool waited = false;
+    };
+    std::deque<Flight> flights;               // in issue order; `waited` is prefix-closed
+    int known0 = 0; std::vector<nik_frame> known;   // slot of frame gid known0 + i: the current push, then the prefetched windows
+    // the planner's hypothetical state behind everything in flight: key frame, next frame to register, predicted next key frame
+    struct Hyp { bool valid = false; int key_gid = -1; nik_frame key_slot = -1; int pos = 0, next_key = 0; std::vector<int> hist; } hyp;
+    std::deque<int> pred;                     // predicted key frames (gids, ascending) not yet decided
+    int plan_key_gid = -2;                    // key of the latest confirmed plan (a second one for the same key: its depth was too short)
+    int la_depth = 2, la_room = 0;            // flights kept in flight; pairs per flight (0: max_batch)   $NIK_TRK_DEPTH / $NIK_TRK_FLIGHT
+
+    nik_frame slot_of(int gid) const { const int i = gid - known0; return (i >= 0 && i < (int)known.size()) ? known[i] : -1; }
+    int known_end() const { return known0 + (int)known.size(); }
+    int unwaited() const { int u = 0; for (const Flight& F : flights) u += !F.waited; return u; }
+    // wait for flight j and everything issued before it
+    int wait_flight(size_t j) {
+        for (size_t i = 0; i <= j && i < flights.size(); ++i) {
+            Flight& F = flights[i];
+            if (F.waited) continue;
+            const int rc = nik_wait_results(ctx, F.res.data(), F.total);
+            if (rc) return rc;
+            F.waited = true;
+        }
+        return NIK_OK;
+    }
+    int drop_flights() {
+        int rc = flights.empty() ? NIK_OK : wait_flight(flights.size() - 1);
+        flights.clear(); pred.clear(); hyp.valid = false;
+        return rc;
+    }
+    // the flight / offset holding ComputePose(key, frame gid), or false
+    bool find(int key_gid, nik_frame key_slot, int gid, size_t& fj, int& off) const {
+        const nik_frame cs = slot_of(gid);
+        for (size_t j = 0; j < flights.size(); ++j)
+            for (const Seg& S : flights[j].segs)
+                if (S.key_gid == key_gid && S.key_slot == key_slot && gid >= S.first_gid && gid < S.first_gid + S.count) {
+                    const int o = S.res_off + (gid - S.first_gid);
+                    if (flights[j].curs[o] == cs) { fj = j; off = o; return true; }
+                }
+        return false;
+    }
+    int issue(Flight& F) {
+        F.total = (int)F.curs.size();
+        if (F.total == 0) return NIK_OK;
+        F.res.resize(F.total);
+        flights.push_back(std::move(F));
+        Flight& G = flights.back();
+        gpu_calls += 1;
+        const int rc = nik_pose_batch_async(ctx, G.total, G.keys.data(), G.curs.data(), 1, G.res.data());
+        if (rc) { (void)nik_wait_results(ctx, G.res.data(), G.total); flights.pop_back(); }      // (chunks already enqueued still write their results)
+        return rc;
+    }
+    void add_seg(Flight& F, int key_gid, nik_frame key_slot, int first, int count) {
+        F.segs.push_back({ key_gid, key_slot, first, count, (int)F.curs.size() });
+        for (int i = 0; i < count; ++i) { F.keys.push_back(key_slot); F.curs.push_back(slot_of(first + i)); }
+    }
+    // continue the guessed chain from `hyp` into F: the frames up to and including the predicted next key frame against the
+    // hypothetical key, then the frames behind that one against it, ... while F has room and frames are known
+    void plan_chain(Flight& F, int room, int max_segs) {
+        for (int c = 0; c < max_segs && hyp.valid; ++c) {
+            const int count = std::min({ hyp.next_key - hyp.pos + 1, room - (int)F.curs.size(), known_end() - hyp.pos });
+            if (count <= 0) break;
+            add_seg(F, hyp.key_gid, hyp.key_slot, hyp.pos, count);
+            hyp.pos += count;
+            if (hyp.pos - 1 != hyp.next_key) break;                  // out of room or of frames: the segment goes on in the next flight
+            hyp.hist.push_back(hyp.next_key - hyp.key_gid);
+            pred.push_back(hyp.next_key);
+            hyp.key_gid = hyp.next_key; hyp.key_slot = slot_of(hyp.key_gid);
+            hyp.next_key = hyp.key_gid + std::max(1, guess_next_gap(hyp.hist));
+        }
+    }
     // Map::_edges (KCC edges between consecutive keyframes, loop edges) and the keyframes' robot poses
     struct EdgeRec { int from, to, type; double T[3]; };     // type 0 = KCC, 1 = Loop; T in camera units (edge->_T)
     std::vector<EdgeRec> edges;
@@ -267,12 +348,17 @@ int nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker*
     nik_tracker* t = new nik_tracker();
     t->ctx = ctx; t->cfg = *cfg; t->H = dims[0]; t->W = dims[1]; t->max_batch = dims[4]; t->max_frames = dims[5];
     for (int s = t->max_frames - 1; s >= 0; --s) t->free_slots.push_back(s);          // pop_back hands out 0, 1, 2, ...
+    if (const char* e = getenv("NIK_TRK_DEPTH")) t->la_depth = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = getenv("NIK_TRK_FLIGHT")) t->la_room = std::max(0, atoi(e));
+    (void)nik_set_lane_rotation(ctx, 1);     // look-ahead batches run side by side on the context's streams ...
+    (void)nik_set_call_depth(ctx, 4);        // ... and none of them makes the host wait for an older one when it is enqueued
     *out = t;
     return NIK_OK;
 }
 
 void nik_tracker_destroy(nik_tracker* t) {
     if (!t) return;
+    (void)t->drop_flights();                 // (their result buffers are written when the calls retire)
     for (uint8_t* p : t->d_up) if (p) (void)nik_dev_free(t->ctx, p);
     delete t;
 }
@@ -355,87 +441,113 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
     std::vector<nik_frame> slot(n);
     if (pre) { slot = t->pre[pi].slots; t->pre.erase(t->pre.begin() + pi); }
     else for (int i = 0; i < n; ++i) { slot[i] = t->free_slots.back(); t->free_slots.pop_back(); }
-    std::vector<nik_pose_result> res(t->max_batch);          // (a batch may hold a frame more than once: once per key segment)
-    std::vector<nik_frame> keys(t->max_batch);
-    int rc, start = 0;
+    int rc;
     memset(out, 0, sizeof(out[0]) * (size_t)n);
-    // on an error: frames that did not become keyframes give their slots back; outputs of unprocessed frames stay zero
-    auto bail = [&](int code) { for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]); return code; };
+    // on an error: nothing stays in flight; frames that did not become keyframes give their slots back; outputs of unprocessed
+    // frames stay zero
+    auto bail = [&](int code) {
+        (void)t->drop_flights();
+        for (int i = n - 1; i >= 0; --i) if (!out[i].inserted) t->free_slots.push_back(slot[i]);
+        return code;
+    };
     // the spectra of a frame do not depend on the keyframe: all n frames in one batch
     if (!pre && (rc = nik_intermedium_batch_dev(t->ctx, n, d_gray, slot.data()))) return bail(rc);
-    if (!t->init) { first_frame(t, slot[0], out[0]); start = 1; }
-    struct Seg { int key_idx, first, count, res_off; };             // key_idx: index into this push (-1: the current keyframe)
-    std::vector<Seg> segs;
-    std::vector<nik_frame> curs(t->max_batch);
-    while (start < n) {
-        // Register the next `depth` frames against the current keyframe in one batch.  The registrations are
-        // speculative: they are valid up to and including the next inserted frame, the ones after it are redone
-        // against the new keyframe.  The depth follows the observed keyframe spacing (twice the last gap), so
-        // little work is thrown away while the batches stay as large as the sequence allows.
-        //
-        // Key-frame chains.  Every keyframe switch would otherwise cost one host round trip of a small, latency-bound batch
-        // (~0.1 ms whatever its size below 16 pairs).  The gaps between keyframes are guessed from their own history
-        // (guess_next_gap: regular spacing and short periodic patterns): the SAME batch also registers the frames behind the
-        // guessed next keyframe against it (every frame's spectra are resident: any frame can serve as a key), and behind the
-        // one guessed after that, and so on while the batch has room.  A guess that turns out right saves the round trip; a
-        // wrong one costs its few pairs of GPU work.  Outputs are exactly those of sequential calls: a speculative result is
-        // used only if its key is the frame the reference's rule really inserted.
-        segs.clear();
-        int total = 0;
-        std::vector<int> hist = t->gap_hist;
-        int guess = nik_tracker::guess_next_gap(hist);             // frames from the current keyframe to the next one (0: no history)
-        // first segment: the frames behind the current keyframe, twice as far as the next keyframe is expected
-        // (never below the adaptive depth: it doubles after a batch without an insertion, so the window still grows towards
-        // max_batch when the key frames suddenly come further apart than their history says)
-        const int depth = std::max(1, guess > 0 ? std::max({ 4, 2 * guess, t->spec_depth }) : t->spec_depth);
-        { const int m0 = std::min({ n - start, depth, t->max_batch });
-          for (int i = 0; i < m0; ++i) { keys[i] = t->key_slot; curs[i] = slot[start + i]; }
-          segs.push_back({ -1, start, m0, 0 }); total = m0; }
-        if (guess > 0) {
-            // frames since the current keyframe that were consumed by earlier calls count towards the gap
-            int kidx = start + guess - 1 - (t->frame_id - 1 - t->key_frame_id);
-            // a guess costs its few registrations, a round trip saved is worth ~25 of them: keep guessing as long as one
-            // guess in four holds; otherwise a single probe per call keeps the rate measured
-            const int max_chain = t->guess_rate >= 0.25 ? 16 : 1;
-            // (the first guessed keyframe must be one of the frames the first segment registers -- that is what confirms it; every
-            // later one is the last frame of the segment before it)
-            for (int c = 0; c < max_chain && kidx >= start && kidx < n - 1 && (c > 0 || kidx < start + segs[0].count); ++c) {
-                hist.push_back(guess);
-                const int next = std::max(1, nik_tracker::guess_next_gap(hist));
-                const int first = kidx + 1;
-                // up to and including the next guessed keyframe; the chain's last segment could go on to twice that
-                int ms = std::min({ n - first, next, t->max_batch - total });
-                if (ms <= 0) break;
-                for (int i = 0; i < ms; ++i) { keys[total + i] = slot[kidx]; curs[total + i] = slot[first + i]; }
-                segs.push_back({ kidx, first, ms, total }); total += ms;
-                if (ms < next) break;                          // out of frames or of batch room: the next guess is not covered
-                guess = next; kidx += next;
-            }
+    // the frames known from here on: this push, then the windows already prefetched (they will be pushed next, in that order)
+    const int gid0 = t->frame_id, end_gid = gid0 + n;
+    t->known0 = gid0; t->known = slot;
+    for (const nik_tracker::Pre& P : t->pre) t->known.insert(t->known.end(), P.slots.begin(), P.slots.end());
+    // batches still in flight from the previous push were planned on its view of the coming frames: they stay usable iff that
+    // view has come true (the window pushed now is the one that had been prefetched first)
+    {
+        bool same = true;
+        for (const nik_tracker::Flight& F : t->flights)
+            for (const nik_tracker::Seg& S : F.segs)
+                for (int i = 0; i < S.count; ++i) {
+                    const int g = S.first_gid + i;
+                    if (g >= gid0 && F.curs[S.res_off + i] != t->slot_of(g)) same = false;
+                    if (S.key_gid >= gid0 && S.key_slot != t->slot_of(S.key_gid)) same = false;
+                }
+        if (t->hyp.valid && t->hyp.key_gid >= gid0 && t->hyp.key_slot != t->slot_of(t->hyp.key_gid)) same = false;
+        if (!same && (rc = t->drop_flights())) return bail(rc);
+    }
+    if (!t->init) first_frame(t, slot[0], out[0]);
+    const int room = std::min(t->max_batch, t->la_room > 0 ? t->la_room : t->max_batch);
+    while (t->frame_id < end_gid) {
+        const int x = t->frame_id;
+        // batches that only hold frames already decided are of no further use
+        while (!t->flights.empty()) {
+            bool behind = true;
+            for (const nik_tracker::Seg& S : t->flights.front().segs) behind = behind && S.first_gid + S.count <= x;
+            if (!behind) break;
+            if ((rc = t->wait_flight(0))) return bail(rc);
+            t->flights.pop_front();
         }
-        if ((rc = nik_pose_batch(t->ctx, total, keys.data(), curs.data(), 1, res.data()))) return bail(rc);
-        t->gpu_calls += 1;
-        size_t sg = 0;
-        for (;;) {
-            const Seg& S = segs[sg];
-            int i = 0; bool inserted = false;
-            const int prev_key_frame = t->key_frame_id;
-            while (i < S.count && !inserted) { inserted = apply_result(t, res[S.res_off + i], slot[S.first + i], out[S.first + i]); ++i; }
-            start = S.first + i;
-            if (inserted) {
-                t->last_gap = std::max(1, t->key_frame_id - prev_key_frame);
-                t->gap_hist.push_back(t->last_gap);
-                if (t->gap_hist.size() > 96) t->gap_hist.erase(t->gap_hist.begin());
-                t->spec_depth = std::min(t->max_batch, std::max(4, 2 * t->last_gap));
-            } else {
+        size_t fj; int off;
+        if (!t->find(t->key_frame_id, t->key_slot, x, fj, off)) {
+            // Nothing in flight registers frame x against the current keyframe: plan from the confirmed state.
+            //
+            // The first segment registers the next `depth` frames against the current keyframe.  The registrations are
+            // speculative: they are valid up to and including the next inserted frame, the ones after it are redone against
+            // the new keyframe.  The depth follows the observed keyframe spacing (twice the guessed gap), so little work is
+            // thrown away while the batches stay as large as the sequence allows.
+            //
+            // Key-frame chains.  Every keyframe switch would otherwise cost one host round trip of a small, latency-bound batch
+            // (~0.1 ms whatever its size below 16 pairs).  The gaps between keyframes are guessed from their own history
+            // (guess_next_gap: regular spacing and short periodic patterns): the SAME batch also registers the frames behind the
+            // guessed next keyframe against it (every frame's spectra are resident: any frame can serve as a key), and behind the
+            // one guessed after that, and so on while the batch has room -- and the batches after it carry the chain on
+            // (plan_chain) while this one runs.
+            t->pred.clear(); t->hyp.valid = false;
+            if (t->plan_key_gid == t->key_frame_id)        // the previous plan for this keyframe ended without an insertion: look further
                 t->spec_depth = std::min(t->max_batch, 2 * std::max(1, t->spec_depth));
+            t->plan_key_gid = t->key_frame_id;
+            const int guess = nik_tracker::guess_next_gap(t->gap_hist);      // frames from the current keyframe to the next one (0: no history)
+            // (never below the adaptive depth: it doubles after a plan without an insertion, so the window still grows towards
+            // max_batch when the key frames suddenly come further apart than their history says)
+            const int depth = std::max(1, guess > 0 ? std::max({ 4, 2 * guess, t->spec_depth }) : t->spec_depth);
+            const int m0 = std::min({ t->known_end() - x, depth, room });
+            nik_tracker::Flight F;
+            t->add_seg(F, t->key_frame_id, t->key_slot, x, m0);
+            // the first guessed keyframe must be one of the frames the first segment registers -- that is what confirms it
+            const int kg = t->key_frame_id + guess;
+            if (guess > 0 && kg >= x && kg < x + m0 && kg < t->known_end() - 1) {
+                t->hyp.valid = true; t->hyp.hist = t->gap_hist;
+                t->hyp.hist.push_back(guess); t->pred.push_back(kg);
+                t->hyp.key_gid = kg; t->hyp.key_slot = t->slot_of(kg); t->hyp.pos = kg + 1;
+                t->hyp.next_key = kg + std::max(1, nik_tracker::guess_next_gap(t->hyp.hist));
+                // a guess costs its few registrations, a round trip saved is worth ~25 of them: keep guessing as long as one
+                // guess in four holds; otherwise a single probe per plan keeps the rate measured
+                t->plan_chain(F, room, t->guess_rate >= 0.25 ? 16 : 1);
+                if (t->guess_rate < 0.25) t->hyp.valid = false;
             }
-            // the next segment is usable iff its guessed key is the frame that has just been inserted
-            if (inserted && sg + 1 < segs.size() && segs[sg + 1].key_idx == start - 1) {
-                ++sg; t->spec_hits += 1; t->guess_rate = 0.9 * t->guess_rate + 0.1;
-                continue;
+            if ((rc = t->issue(F))) return bail(rc);
+            continue;
+        }
+        if (!t->flights[fj].waited) {
+            // about to block on a batch: first hand the GPU the batches behind it (the chain carried on from the planner's state)
+            while (t->hyp.valid && t->unwaited() < t->la_depth && t->hyp.pos < t->known_end()) {
+                nik_tracker::Flight F;
+                t->plan_chain(F, room, 16);
+                if (F.curs.empty()) break;
+                if ((rc = t->issue(F))) return bail(rc);
             }
-            if (sg + 1 < segs.size()) { t->spec_misses += 1; t->guess_rate = 0.9 * t->guess_rate; }
-            break;
+            if ((rc = t->wait_flight(fj))) return bail(rc);
+        }
+        const int prev_key_frame = t->key_frame_id;
+        const nik_pose_result r = t->flights[fj].res[off];
+        const bool inserted = apply_result(t, r, slot[x - gid0], out[x - gid0]);
+        if (inserted) {
+            t->last_gap = std::max(1, t->key_frame_id - prev_key_frame);
+            t->gap_hist.push_back(t->last_gap);
+            if (t->gap_hist.size() > 96) t->gap_hist.erase(t->gap_hist.begin());
+            t->spec_depth = std::min(t->max_batch, std::max(4, 2 * t->last_gap));
+        }
+        // the guesses: a predicted keyframe must be inserted, and nothing before it
+        if (!t->pred.empty() && (inserted || t->pred.front() == x)) {
+            if (inserted && t->pred.front() == x) { t->pred.pop_front(); t->spec_hits += 1; t->guess_rate = 0.9 * t->guess_rate + 0.1; }
+            else { t->pred.clear(); t->hyp.valid = false; t->spec_misses += 1; t->guess_rate = 0.9 * t->guess_rate; }
+        } else if (inserted) {
+            t->hyp.valid = false;                       // (an insertion nobody predicted: whatever the planner assumed is off)
         }
     }
     // recycle the slots of frames that did not become keyframes
@@ -446,6 +558,7 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
 int nik_tracker_push_u8(nik_tracker* t, const uint8_t* gray, int stride, nik_track_output* out) {
     if (!t || !gray || !out) return NIK_ERR_INVALID_ARG;
     if (t->free_slots.empty()) return NIK_ERR_CAPACITY;
+    { const int rcf = t->drop_flights(); if (rcf) return rcf; }      // (look-ahead batches belong to the batched entry point)
     // host frame: upload through the single-frame entry point, then run the same logic with the spectra in place
     const nik_frame s = t->free_slots.back();
     int rc = nik_intermedium_u8(t->ctx, gray, stride, s);

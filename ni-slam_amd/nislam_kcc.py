@@ -29,7 +29,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_device", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
-           "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
+           "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_wait_results", "nik_set_lane_rotation", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
            "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_guess_gap", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
@@ -198,6 +198,8 @@ def load():
         L.nik_pose.argtypes = [P, I, I, I, P, P, P]
         L.nik_pose_batch.argtypes = [P, I, P, P, I, P]
         L.nik_pose_batch_async.argtypes = [P, I, P, P, I, P]
+        L.nik_wait_results.argtypes = [P, P, I]
+        L.nik_set_lane_rotation.argtypes = [P, I]
         L.nik_track_batch_dev.argtypes = [P, I, P, P, P, I, P, I]
         L.nik_match.argtypes = [P, I, I, P, P, P, P]
         L.nik_match_topk.argtypes = [P, I, I, P, I, P, P, P]
@@ -719,22 +721,30 @@ class Tracker:
             raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
         return [o.as_dict() for o in out]
 
+    def push_dev_into(self, d_gray_ptr, n, out, offset=0):
+        """nik_tracker_push_dev writing into out[offset : offset + n] of a caller-owned (NikTrackOutput * N)() array -- what a C
+        caller does; no per-frame Python objects (as_dict on 2048 outputs costs as much as 20 % of the sequence workload)"""
+        rc = self._L.nik_tracker_push_dev(self._t, int(n), C.c_void_p(int(d_gray_ptr)), C.c_void_p(C.addressof(out) + int(offset) * C.sizeof(NikTrackOutput)))
+        if rc:
+            raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
+
     def prefetch_dev(self, d_gray_ptr, n):
         """start ComputeIntermedium of the window that will be pushed NEXT (same pointer, same n): nik_tracker_prefetch_dev"""
         rc = self._L.nik_tracker_prefetch_dev(self._t, int(n), C.c_void_p(int(d_gray_ptr)))
         if rc:
             raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
 
-    def push_host(self, frames, ptr=None):
+    def push_host(self, frames, ptr=None, raw=False):
         """n host frames [n][H][W] u8 (numpy, or the address `ptr` of pinned memory holding them): windows of max_batch frames,
-        the next window uploaded while the current one is registered (nik_tracker_push_host)"""
+        the next window uploaded while the current one is registered (nik_tracker_push_host).  raw: return the ctypes output
+        array itself (what a C caller holds) instead of one dict per frame"""
         n, H, W = frames.shape
         out = (NikTrackOutput * n)()
         src = C.c_void_p(int(ptr)) if ptr is not None else _p(np.ascontiguousarray(frames, np.uint8))
         rc = self._L.nik_tracker_push_host(self._t, int(n), src, int(W), int(H) * int(W), C.cast(out, C.c_void_p))
         if rc:
             raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
-        return [o.as_dict() for o in out]
+        return out if raw else [o.as_dict() for o in out]
 
     def push_u8(self, gray):
         gray = np.ascontiguousarray(gray, np.uint8)
