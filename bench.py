@@ -459,14 +459,14 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     nkey = int(sum(o["inserted"] for o in outs))
     bpf = algorithmic_bytes(H, W, PD, PC, kzz_cached=True)
     return _line("frames/s through the tracker (configs[1] as a sequence)", "frames/s", T / best, 1, args, 1e3 * best,
-                 "configs[1] sequence: %d frames (%s camera path), C++ tracker (keyframe rule, PSR gating), speculative windows of %d, Kzz cached per keyframe" % (T, args.seq_motion, win),
+                 "configs[1] sequence: %d frames (%s camera path), C++ tracker (keyframe rule, PSR gating), windows of %d frames, look-ahead batches along the guessed keyframe chain, Kzz cached per keyframe" % (T, args.seq_motion, win),
                  bpf, dict(frames=T, window=win, keyframes=nkey, good_tracking=int(sum(o["good_tracking"] for o in outs)),
                            keyframe_guesses_held=spec_box[0], keyframe_guesses_failed=spec_box[1], batched_pose_calls=spec_box[2]),
                  parity_spot_check=parity, roofline=None, cpu_baseline=None,
                  hipgraph={"frames_per_s_off": round(T / best_off, 1), "frames_per_s_on": round(T / best_g, 1),
                            "identical_outputs": bool(graphs_same), "reported": "on" if use_g else "off"},
                  host_inclusive=host,
-                 note="a keyframe switch is a dependent round trip of a small batch unless the tracker guessed the new keyframe from the history of gaps and registered the frames behind it in the same batch (nik_tracker_guess_gap); all outputs equal one-frame-at-a-time pushes")
+                 note="the tracker guesses the coming keyframes from the history of their gaps (nik_tracker_guess_gap) and keeps asynchronous pose batches planned along that chain in flight while it applies the previous one; a result is used only if its key is the frame the reference's rule really inserted: all outputs equal one-frame-at-a-time pushes (parity_spot_check compares every frame)")
 
 
 def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
