@@ -29,6 +29,7 @@ struct nik_ctx {
     struct Pending { nik_pose_result* res; std::vector<nik_pose_result> val; };
     std::deque<Pending> pending;
     long issued = 0, pairs = 0, early_reads = 0;
+    long fail_at = -1;                           // nik_pose_batch_async number `fail_at` fails once (an injected device error)
 };
 struct nik_map { int unused; };
 
@@ -78,6 +79,7 @@ int nik_pose(nik_ctx* c, nik_frame key, nik_frame cur, int, double pose[3], doub
 }
 int nik_pose_batch_async(nik_ctx* c, int n, const nik_frame* keys, const nik_frame* curs, int, nik_pose_result* res) {
     if (n <= 0 || n > c->max_batch) return NIK_ERR_CAPACITY;
+    if (c->issued == c->fail_at) { c->fail_at = -1; return NIK_ERR_HIP; }
     nik_ctx::Pending P; P.res = res; P.val.resize(n);
     for (int i = 0; i < n; ++i) P.val[i] = pose_of(c, keys[i], curs[i]);
     memset(res, 0xFF, sizeof(nik_pose_result) * (size_t)n);                  // not final until waited for
@@ -182,6 +184,40 @@ Run run(const std::vector<uint8_t>& frames, int n, int window, int mode, int dep
     return R;
 }
 
+bool same(const nik_track_output& a, const nik_track_output& b);
+
+// an injected failure of batch number `fail_at`: the push returns the error, nothing stays in flight, the frames decided before
+// it equal the reference's, the undecided ones are zero -- and pushing again from the first undecided frame carries on exactly
+// as if nothing had happened (the tracker's state is only ever advanced by results it has applied, in frame order)
+bool run_with_failure(const std::vector<uint8_t>& frames, int n, int window, int depth, long fail_at, const std::vector<nik_track_output>& ref) {
+    char b[32];
+    snprintf(b, sizeof b, "%d", depth); setenv("NIK_TRK_DEPTH", b, 1); setenv("NIK_TRK_FLIGHT", "0", 1);
+    nik_ctx ctx; ctx.max_batch = window; ctx.max_frames = n + 3 * window + 2; ctx.content.assign(ctx.max_frames, -1); ctx.fail_at = fail_at;
+    const nik_tracker_config cfg = config();
+    nik_tracker* t = nullptr;
+    if (nik_tracker_create(&ctx, &cfg, &t)) return false;
+    std::vector<nik_track_output> out(n);
+    const size_t fb = (size_t)FH * FW;
+    bool ok = true, failed = false;
+    for (int b0 = 0; b0 < n && ok;) {
+        const int m = std::min(window, n - b0);
+        const int rc = nik_tracker_push_dev(t, m, frames.data() + b0 * fb, out.data() + b0);
+        int done = m;
+        if (rc) {
+            ok = ok && rc == NIK_ERR_HIP && !failed && ctx.pending.empty();
+            failed = true;
+            done = 0;
+            while (done < m && (b0 + done == 0 ? out[0].inserted != 0 : out[b0 + done].frame_id == b0 + done)) ++done;
+            for (int i = done; i < m; ++i) { nik_track_output z; memset(&z, 0, sizeof z); ok = ok && !memcmp(&out[b0 + i], &z, sizeof z); }
+        }
+        b0 += done;
+        if (rc && done == 0 && m == 0) break;
+    }
+    for (int i = 0; i < n && ok; ++i) ok = same(out[i], ref[i]);
+    nik_tracker_destroy(t);
+    return ok && failed && ctx.pending.empty();
+}
+
 bool same(const nik_track_output& a, const nik_track_output& b) {
     return a.frame_id == b.frame_id && a.inserted == b.inserted && a.good_tracking == b.good_tracking && a.key_frame_id == b.key_frame_id &&
            !memcmp(a.response, b.response, sizeof a.response) && !memcmp(a.cf_pose, b.cf_pose, sizeof a.cf_pose) &&
@@ -221,6 +257,16 @@ int main(int argc, char** argv) {
                                 printf("seed %u window 64 prefetch depth %d: %d keyframes, %ld batched calls, %ld pairs registered for %d frames, guesses %ld held / %ld failed\n",
                                        seed, depth, nkey, r.calls, r.pairs, n, r.held, r.failed);
                         }
+    }
+    {
+        const std::vector<uint8_t> frames = make_sequence(n, 5);
+        const Run ref = run(frames, n, 1, 4, 1, 0);
+        int inj = 0;
+        for (int w : { 8, 32 }) for (int depth = 1; depth <= 3; ++depth) for (long at : { 0L, 1L, 2L, 5L, 17L, 40L }) {
+            inj += 1;
+            if (!run_with_failure(frames, n, w, depth, at, ref.out)) { printf("FAIL: injected failure of batch %ld (window %d depth %d) not survived\n", at, w, depth); bad += 1; }
+        }
+        printf("injected failures: %d cases\n", inj);
     }
     printf("%s: %d configurations, %d differ\n", bad ? "FAIL" : "OK", cases, bad);
     return bad ? 1 : 0;

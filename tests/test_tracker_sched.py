@@ -2,7 +2,9 @@
 -- asynchronous batches whose results arrive only when waited for, a deterministic ComputePose -- and driven over sequences with
 regular, periodic and irregular keyframe gaps, PSR-gated insertions and lost frames.  1176 combinations of window size, look-ahead
 depth, batch room, prefetching (none / one / two windows), ragged windows and the host-frame entry point must all give, bit for
-bit, the outputs of one nik_tracker_push_u8 per frame: MapBuilder::AddNewInput's loop (src/map_builder.cc:30-70)."""
+bit, the outputs of one nik_tracker_push_u8 per frame: MapBuilder::AddNewInput's loop (src/map_builder.cc:30-70).  36 more runs
+inject a failing batch: the push reports it, nothing stays in flight, and pushing again from the first undecided frame carries on
+exactly."""
 import os
 import shutil
 import subprocess

@@ -11,7 +11,7 @@ db = sqlite3.connect(sys.argv[1])
 rows = db.execute("select start, end, name, grid_x, workgroup_x from kernels order by start").fetchall()
 runs, cur, ce = [], [rows[0]], rows[0][1]
 for r in rows[1:]:
-    if r[0] - ce > 1.5e6:
+    if r[0] - ce > float(__import__("os").environ.get("GAP", "1.5e6")):
         runs.append(cur); cur = []
     cur.append(r); ce = max(ce, r[1])
 runs.append(cur)
