@@ -237,13 +237,19 @@ typedef struct {
     int32_t reserved_;
 } nik_track_output;
 
-/* replaces MapBuilder::MapBuilder's tracking members (map_builder.cc:18-28); the tracker borrows ctx */
+/* replaces MapBuilder::MapBuilder's tracking members (map_builder.cc:18-28); the tracker borrows ctx (which must outlive it)
+ * and configures it for its batches: nik_set_lane_rotation(ctx, 1), nik_set_call_depth(ctx, 4). */
 int  nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker** out);
 void nik_tracker_destroy(nik_tracker* t);
 /* replaces MapBuilder::AddNewInput (map_builder.cc:30-70) minus undistortion / map / loop closure, for n
  * consecutive frames already in HBM (u8, [n][H][W]).  Frames are registered speculatively against the current
  * keyframe in one batch and re-registered after every keyframe switch, so the outputs are exactly those of n
- * sequential calls.  n <= max_batch of the context. */
+ * sequential calls.  n <= max_batch of the context.
+ * Look-ahead batches: the coming keyframes are guessed from the history of their gaps, and asynchronous pose batches planned
+ * along that chain ($NIK_TRK_DEPTH of them, default 2, of at most $NIK_TRK_FLIGHT pairs, default max_batch) stay in flight --
+ * also across calls, over the frames of windows already handed to nik_tracker_prefetch_dev -- while the previous batch's
+ * results are applied.  A result is used only if its key is the frame the rule above really made the keyframe; a wrong guess
+ * wastes its GPU work, never changes an output.  The `out` array of a call is complete when the call returns. */
 int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out);
 /* ComputeIntermedium of the NEXT window started now (it does not depend on the key frame): it runs beside the current window's
  * registrations; the nik_tracker_push_dev with the same pointer and n picks the spectra up (at most two windows under way).
