@@ -398,7 +398,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
             trk.push_dev_into(base + b0 * fb, m, raw, b0)
         dt = time.perf_counter() - t1
         outs = [o.as_dict() for o in raw]
-        spec_box[:] = trk.speculation()
+        spec_box[:] = trk.speculation(); stats_box.update(trk.stats())
         trk.close(); flow.close()
         return outs, dt
     def run_host(nframes, src, ptr=None):
@@ -414,7 +414,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
         outs = [o.as_dict() for o in raw]
         trk.close(); flow.close()
         return outs, dt
-    spec_box = [0, 0, 0]
+    spec_box = [0, 0, 0]; stats_box = {}
     run(min(T, 256))                                            # warm-up (module load, first launches)
     best, best_g = None, None
     for _ in range(max(1, args.steps // 10)):
@@ -461,7 +461,7 @@ def workload_sequence(args, N, torch, np, synth, dev, local_rank):
     return _line("frames/s through the tracker (configs[1] as a sequence)", "frames/s", T / best, 1, args, 1e3 * best,
                  "configs[1] sequence: %d frames (%s camera path), C++ tracker (keyframe rule, PSR gating), windows of %d frames, look-ahead batches along the guessed keyframe chain, Kzz cached per keyframe" % (T, args.seq_motion, win),
                  bpf, dict(frames=T, window=win, keyframes=nkey, good_tracking=int(sum(o["good_tracking"] for o in outs)),
-                           keyframe_guesses_held=spec_box[0], keyframe_guesses_failed=spec_box[1], batched_pose_calls=spec_box[2]),
+                           keyframe_guesses_held=spec_box[0], keyframe_guesses_failed=spec_box[1], batched_pose_calls=spec_box[2], registrations=stats_box),
                  parity_spot_check=parity, roofline=None, cpu_baseline=None,
                  hipgraph={"frames_per_s_off": round(T / best_off, 1), "frames_per_s_on": round(T / best_g, 1),
                            "identical_outputs": bool(graphs_same), "reported": "on" if use_g else "off"},

@@ -251,6 +251,9 @@ void nik_tracker_destroy(nik_tracker* t);
  * results are applied.  A result is used only if its key is the frame the rule above really made the keyframe; a wrong guess
  * wastes its GPU work, never changes an output.  The `out` array of a call is complete when the call returns. */
 int  nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track_output* out);
+/* diagnostics of the look-ahead batches: [guesses held, guesses failed, batches enqueued, registrations enqueued, registrations
+ * consumed, registrations of batches still in flight when a guess failed, 0, 0] (the first three: nik_tracker_speculation) */
+int  nik_tracker_stats(const nik_tracker* t, long out[8]);
 /* ComputeIntermedium of the NEXT window started now (it does not depend on the key frame): it runs beside the current window's
  * registrations; the nik_tracker_push_dev with the same pointer and n picks the spectra up (at most two windows under way).
  * Outputs unchanged. */

@@ -56,6 +56,7 @@ struct nik_tracker {
     std::vector<int> gap_hist;               // the recent keyframe gaps, oldest first (what the next gaps are guessed from)
     double guess_rate = 0.5;                 // running share of keyframe guesses that held
     long spec_hits = 0, spec_misses = 0, gpu_calls = 0;      // diagnostics (nik_tracker_speculation)
+    long pairs_issued = 0, pairs_used = 0, pairs_behind_miss = 0;   // registrations enqueued / consumed / still in flight when a guess failed (nik_tracker_stats)
 
     // The gap that followed the most recent earlier occurrence of the current context -- the last sixteen gaps, else the last
     // fifteen, ... else the last one; without any such occurrence, the last gap again.  Regular spacing and periodic patterns
@@ -141,7 +142,7 @@ struct nik_tracker {
         F.res.resize(F.total);
         flights.push_back(std::move(F));
         Flight& G = flights.back();
-        gpu_calls += 1;
+        gpu_calls += 1; pairs_issued += G.total;
         const int rc = nik_pose_batch_async(ctx, G.total, G.keys.data(), G.curs.data(), 1, G.res.data());
         if (rc) { (void)nik_wait_results(ctx, G.res.data(), G.total); flights.pop_back(); }      // (chunks already enqueued still write their results)
         return rc;
@@ -389,6 +390,15 @@ int nik_tracker_speculation(const nik_tracker* t, long out[3]) {
     return NIK_OK;
 }
 
+// more diagnostics: [guesses held, guesses failed, batches, registrations enqueued, registrations consumed, registrations of batches
+// still in flight when a guess failed (their work is wasted), 0, 0]
+int nik_tracker_stats(const nik_tracker* t, long out[8]) {
+    if (!t || !out) return NIK_ERR_INVALID_ARG;
+    const long v[8] = { t->spec_hits, t->spec_misses, t->gpu_calls, t->pairs_issued, t->pairs_used, t->pairs_behind_miss, 0, 0 };
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return NIK_OK;
+}
+
 // the tracker's guess of the next keyframe gap from a history of gaps (oldest first); exported for the tests
 int nik_tracker_guess_gap(const int32_t* gaps, int n) {
     if (!gaps || n <= 0) return 0;
@@ -538,6 +548,7 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
         }
         const int prev_key_frame = t->key_frame_id;
         const nik_pose_result r = t->flights[fj].res[off];
+        t->pairs_used += 1;
         const bool inserted = apply_result(t, r, slot[x - gid0], out[x - gid0]);
         if (inserted) {
             t->last_gap = std::max(1, t->key_frame_id - prev_key_frame);
@@ -548,7 +559,10 @@ int nik_tracker_push_dev(nik_tracker* t, int n, const uint8_t* d_gray, nik_track
         // the guesses: a predicted keyframe must be inserted, and nothing before it
         if (!t->pred.empty() && (inserted || t->pred.front() == x)) {
             if (inserted && t->pred.front() == x) { t->pred.pop_front(); t->spec_hits += 1; t->guess_rate = 0.9 * t->guess_rate + 0.1; }
-            else { t->pred.clear(); t->hyp.valid = false; t->spec_misses += 1; t->guess_rate = 0.9 * t->guess_rate; }
+            else {
+                t->pred.clear(); t->hyp.valid = false; t->spec_misses += 1; t->guess_rate = 0.9 * t->guess_rate;
+                for (const nik_tracker::Flight& F : t->flights) if (!F.waited) t->pairs_behind_miss += F.total;
+            }
         } else if (inserted) {
             t->hyp.valid = false;                       // (an insertion nobody predicted: whatever the planner assumed is off)
         }

@@ -31,7 +31,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
            "nik_downsample_u8_stream", "nik_downsample_pyr_u8_stream", "nik_stream_wait_ctx", "nik_ctx_wait_stream", "nik_set_call_depth", "nik_pose_batch_async", "nik_wait_results", "nik_set_lane_rotation", "nik_map_create", "nik_map_destroy", "nik_map_add_frame", "nik_map_size", "nik_map_candidates", "nik_map_find_loop",
            "nik_host_polar_plan", "nik_host_free", "nik_host_rot_terms", "nik_host_rot8_geom", "nik_device",
-           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_guess_gap", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
+           "nik_set_residual_stats", "nik_residual_stats_dev", "nik_residual_stats", "nik_tracker_pending_loops", "nik_tracker_speculation", "nik_tracker_stats", "nik_tracker_guess_gap", "nik_tracker_poses", "nik_tracker_edges", "nik_tracker_optimizations", "nik_map_update_poses", "nik_pose_batch_chained", "nik_wait_for", "nik_downsample_u8_async", "nik_set_graphs",
            "nik_group_last_error", "nik_group_unique_id", "nik_group_create_rank", "nik_group_create_local", "nik_group_destroy",
            "nik_group_world", "nik_group_local_count", "nik_group_ctx", "nik_group_rank", "nik_rgb_to_gray_async", "nik_group_shard", "nik_group_pick_best", "nik_group_comm_ranks",
            "nik_group_allreduce_residual", "nik_group_residual_result", "nik_group_gather_best", "nik_group_track_batch",
@@ -727,6 +727,13 @@ class Tracker:
         rc = self._L.nik_tracker_push_dev(self._t, int(n), C.c_void_p(int(d_gray_ptr)), C.c_void_p(C.addressof(out) + int(offset) * C.sizeof(NikTrackOutput)))
         if rc:
             raise NikError(rc, self._L.nik_last_error(self._flow._ctx).decode())
+
+    def stats(self):
+        """nik_tracker_stats: dict of the look-ahead diagnostics"""
+        out = (C.c_long * 8)()
+        self._L.nik_tracker_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self._L.nik_tracker_stats(self._t, out)
+        return dict(guesses_held=out[0], guesses_failed=out[1], batches=out[2], pairs_enqueued=out[3], pairs_consumed=out[4], pairs_in_flight_behind_failed_guesses=out[5])
 
     def prefetch_dev(self, d_gray_ptr, n):
         """start ComputeIntermedium of the window that will be pushed NEXT (same pointer, same n): nik_tracker_prefetch_dev"""
