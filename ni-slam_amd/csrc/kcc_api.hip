@@ -133,6 +133,7 @@ struct nik_ctx {
     int last_pose_n = -1, last_pose_nhyp = 0, last_pose_nc = 0;   // shape of the latest pose call (nik_pose_batch_chained checks it)
     hipStream_t stats_stream = nullptr; hipEvent_t stats_done = nullptr; bool stats_pending = false;
     int graph_max = 0;                   // batches of <= graph_max pairs replay a captured hipGraph (0: off); $NIK_GRAPH
+    int lane_items = 32;                 // a call of n items is spread over n / lane_items streams ($NIK_LANE_ITEMS)
     bool lane_rot = false; int lane_base = 0;   // nik_set_lane_rotation: successive calls start on successive lanes (several small calls in flight run side by side)
     hipEvent_t fence_ev = nullptr;       // nik_wait_for
     hipEvent_t chain_ev[4] = { nullptr, nullptr, nullptr, nullptr };   // a finer pyramid level has read lane li's surface results
@@ -711,7 +712,7 @@ inline void chunk_of(int n, int nl, int li, int& b, int& e) {
 }
 // a lane is worth its cross-stream bookkeeping (and the doubled launch count) only with >= 32 items to run: measured,
 // batches of 32 are faster on one stream (pyramid workload 16.3 k -> 19.5 k pairs/s)
-inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->active_lanes, n / 32)); }
+inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->active_lanes, n / c->lane_items)); }
 
 int lane_alloc(nik_ctx* c, Lane& L, int nl) {
     L.cap_items = c->max_items;
@@ -837,6 +838,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     if (const char* e = getenv("NIK_ALT_ORDER")) c->alt_order = atoi(e) != 0;
     if (const char* e = getenv("NIK_FUSE_FIX_ZERO")) c->fuse_fix_zero = atoi(e) != 0;
     if (const char* e = getenv("NIK_CHUNK")) c->chunk_pairs = std::max(0, atoi(e));
+    if (const char* e = getenv("NIK_LANE_ITEMS")) c->lane_items = std::max(1, atoi(e));
     if (const char* e = getenv("NIK_GRAPH")) c->graph_max = std::max(0, atoi(e));
     c->slot_kind.assign(max_frames, 0);
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
