@@ -176,7 +176,7 @@ template <> struct PlanFor<320> : Plan<320, 16, 20> {};
 template <> struct PlanFor<480> : Plan<480, KCC_P480> {};
 template <> struct PlanFor<640> : Plan<640, KCC_P640> {};
 #ifndef KCC_P1280
-#define KCC_P1280 8, 10, 16
+#define KCC_P1280 20, 8, 8
 #endif
 template <> struct PlanFor<1280> : Plan<1280, KCC_P1280> {};
 // reference configs/config_geekplus.yaml (448 x 448) and configs/config_HD.yaml (1600 x 1200)
@@ -194,6 +194,12 @@ template <int N> struct PlanAlt : PlanFor<N> {};
 #define KCC_PA640 20, 32
 #endif
 template <> struct PlanAlt<640> : Plan<640, KCC_PA640> {};
+// 1280 points: the two-plane kernels (PlanFor) and the single-plane ones want different plans (HD workload, kB<1280,*> ms per 128 pairs:
+// solve_inv / fwd_mul_inv / fwd_abs_inv = 0.437 / 0.385 / 0.284 with 8 x 10 x 16 everywhere, 0.406 / 0.354 / 0.330 with 20 x 8 x 8)
+#ifndef KCC_PA1280
+#define KCC_PA1280 8, 10, 16
+#endif
+template <> struct PlanAlt<1280> : Plan<1280, KCC_PA1280> {};
 // (measured and not adopted: 1280 = 32 x 40 / 40 x 32 for the single-plane 1280-point kernels -- fwd_abs_inv 0.30 -> 0.34 / 0.37 ms;
 // 480 = 16 x 30 for the Kzz-cached 480-point kernels -- 122.7 k -> 118.3 k candidates/s)
 
