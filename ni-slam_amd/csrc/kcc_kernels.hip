@@ -1300,7 +1300,8 @@ void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 template <int HH> static void launchA_fwd_u8_t(hipStream_t s, int n_items, AArgs a) {
     a.n_items = n_items;
     const int nbx = a.cols / FCfg<HH>::LX;
-    int tpw = KCC_U8_TPW;
+    static const int tpw_env = [] { const char* e = getenv("NIK_U8_TPW"); return e ? atoi(e) : 0; }();
+    int tpw = tpw_env > 0 ? tpw_env : KCC_U8_TPW;
     while (tpw > 1 && nbx % tpw) --tpw;                      // tiles per workgroup must divide the tiles of an image
     dim3 grid((nbx / tpw) * n_items), block(FCfg<HH>::NT);
     const size_t bytes = FCfg<HH>::BYTES;
