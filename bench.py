@@ -215,6 +215,17 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
             cf.set_residual_stats(True)
             stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
             comm = "FALLBACK torch.distributed all-reduce (nik_group failed: %s)" % str(e)[:200]
+        if world > 1:
+            # every rank must take the same road: a communicator that formed on some ranks only would leave them waiting in RCCL
+            # for the ranks that fell back to torch.distributed
+            ok = torch.tensor([0 if fallback else 1], dtype=torch.int32, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and grp is not None:
+                grp.close()
+                grp, fallback = None, True
+                cf.set_residual_stats(True)
+                stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
+                comm = "FALLBACK torch.distributed all-reduce (nik_group failed on another rank)"
 
     # The library keeps two calls in flight per stream; results of step k are final once step k+2 has been queued (or after
     # synchronize()).  Nothing in the loop touches per-pair results on the host.
