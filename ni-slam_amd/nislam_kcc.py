@@ -455,6 +455,25 @@ class CorrelationFlow:
                                          C.cast(res, C.c_void_p)))
         return [r.as_dict() for r in res]
 
+    def pose_batch_async(self, keys, curs, not_large_rotation=True, res=None):
+        """nik_pose_batch_async over stored frames: returns the (NikPoseResult * n) array, final after wait_results(res) or
+        synchronize(); keep it alive until then"""
+        n = len(keys)
+        res = res if res is not None else (NikPoseResult * n)()
+        k, c = _i32(keys), _i32(curs)
+        self._chk(self._L.nik_pose_batch_async(self._ctx, n, _p(k), _p(c), int(bool(not_large_rotation)), C.cast(res, C.c_void_p)))
+        keep = self.__dict__.setdefault("_inflight", [])
+        keep.append(res)
+        del keep[:-16]
+        return res
+
+    def wait_results(self, res):
+        """nik_wait_results: the results of ONE asynchronous batch (later batches keep running)"""
+        self._chk(self._L.nik_wait_results(self._ctx, C.cast(res, C.c_void_p), len(res)))
+
+    def set_lane_rotation(self, on=True):
+        self._chk(self._L.nik_set_lane_rotation(self._ctx, int(bool(on))))
+
     def track_batch_dev(self, d_gray_ptr, keys, cur_dst, not_large_rotation=True, sync=True, res=None):
         keys, cur_dst = _i32(keys), _i32(cur_dst)
         n = len(keys)

@@ -16,7 +16,7 @@ import pytest
 
 import kcc_helpers
 import synth
-from kcc_helpers import FULL, ROOT, check_pose_parity, nik
+from kcc_helpers import FULL, ROOT, SMALL, check_pose_parity, nik
 from oracle import kcc_oracle as ko
 
 pytestmark = pytest.mark.gpu
@@ -357,3 +357,42 @@ def test_smooth_content_translation_near_ties():
                                                      translation_near_ties_verified=near, gaps=gaps, tie_rel=TRANS_TIE_REL))
     assert exact + ties + near == n
     cf.close()
+
+
+@pytest.mark.gpu
+def test_wait_results_and_lane_rotation():
+    """nik_pose_batch_async + nik_wait_results: several batches in flight with their own result buffers, consumed one at a time
+    (what kcc_tracker.cpp's look-ahead batches do); with and without nik_set_lane_rotation the results equal the synchronous
+    call's, a buffer is final after its own wait while later batches are still queued, and waiting twice / after a synchronize
+    is harmless"""
+    import torch
+    N = nik()
+    geom = SMALL
+    H, W = geom["H"], geom["W"]
+    cfg = N.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"])
+    nf = 48
+    keys_u8, curs_u8, _ = synth.make_batch(nf, H, W, seed0=321, max_shift=8, max_theta=6.0)
+    frames = np.concatenate([keys_u8, curs_u8])
+    d = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+    for rot in (False, True):
+        for streams in (1, 3):
+            cf = N.CorrelationFlow(cfg, H, W, max_batch=nf, max_frames=2 * nf)
+            cf.set_streams(streams); cf.set_lane_rotation(rot)
+            cf._chk(cf._L.nik_set_call_depth(cf._ctx, 4))
+            cf.intermedium_batch_dev(d.data_ptr(), nf, list(range(nf)))
+            cf.intermedium_batch_dev(d.data_ptr() + nf * H * W, nf, list(range(nf, 2 * nf)))
+            # batches of different sizes over overlapping frames, keys used by several batches
+            plans = [(list(range(0, 40)), list(range(nf, nf + 40))), ([3] * 7, list(range(nf + 5, nf + 12))), (list(range(8, 48)), list(range(nf + 8, nf + 48))),
+                     ([0, 1], [nf + 1, nf]), (list(range(0, 33)), list(range(nf + 10, nf + 43)))]
+            want = [cf.pose_batch(k, c, True) for k, c in plans]
+            for order in ((0, 1, 2, 3, 4), (4, 3, 2, 1, 0), (2, 0, 4, 1, 3)):
+                bufs = [cf.pose_batch_async(k, c, True) for k, c in plans]
+                for i in order:
+                    cf.wait_results(bufs[i])
+                    got = [r.as_dict() for r in bufs[i]]
+                    assert got == want[i], (rot, streams, order, i)
+                cf.wait_results(bufs[0])                                  # nothing left to wait for
+                cf.synchronize()
+                cf.wait_results(bufs[2])
+                assert all([r.as_dict() for r in b] == w for b, w in zip(bufs, want))
+            cf.close()
