@@ -24,16 +24,25 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# units whose code depends on the -DKCC_* tuning macros: a variant rebuilds only these and links the base objects of the rest
+VARIANT_UNITS = ("kcc_kernels.hip", "kcc_generic.hip")
+
+
 def build(force=False, verbose=False, defs=(), suffix=""):
-    """defs/suffix: tuning variants, e.g. build(defs=["-DKCC_P360=15,24"], suffix="_p360b") -> lib..._p360b.so"""
+    """defs/suffix: tuning variants, e.g. build(defs=["-DKCC_P360=15,24"], suffix="_p360b") -> lib..._p360b.so
+    (variant objects live in csrc/_var/, git-ignored; only VARIANT_UNITS are recompiled for a variant)"""
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     objs = []
     lib = LIB.replace(".so", suffix + ".so")
+    if suffix:
+        build(force=False, verbose=verbose)          # the base objects the variant links
+        os.makedirs(os.path.join(CSRC, "_var"), exist_ok=True)
     for src, extra in UNITS:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, os.path.splitext(src)[0] + suffix + ".o")
+        var = bool(suffix) and (src in VARIANT_UNITS)
+        o = os.path.join(CSRC, "_var", os.path.splitext(src)[0] + suffix + ".o") if var else os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
         if force or _stale(o, [s] + hdrs):
-            cmd = [HIPCC] + COMMON + extra + list(defs) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + COMMON + extra + (list(defs) if var else []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -1684,7 +1684,295 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// B-type kernels, ring form (round 5): persistent workgroups fed by a loader wave through LDS-DMA
+// ------------------------------------------------------------------------------------------------
+// The kB kernels above load a tile's spectrum lines into registers (8 bytes per lane) at the start of a workgroup's life and
+// nothing is in flight while the workgroup transforms: memory time and arithmetic time ADD.  Every attempt to
+// prefetch the next tile paid in VGPRs -- hence in waves.  LDS-DMA costs none: a persistent workgroup is LK lines of
+// consumer threads plus ONE loader wave that requests the NEXT tile's lines with global_load_lds_dwordx4 (16 bytes per lane,
+// a line is contiguous in the k-major spectrum: the ideal DMA shape) while the consumers transform the current one.  LDS
+// holds two SETS of plane buffers; a set receives a tile's input lines in natural order, the consumers pick their first-pass
+// points out of it (ds_read_b64, consecutive lanes: conflict-free), and from then on the same set serves as the tile's
+// exchange buffers -- the staging costs no LDS beyond the second set.  The loader wave owns the only vmcnt that counts DMAs
+// (a wave's loads return in order: a consumer that issued DMAs would wait for them at its next twiddle load), executes the
+// consumers' barriers with them (K per tile, counted at compile time) and does its s_waitcnt vmcnt(0) right before the tile's
+// first barrier.  Same arithmetic, same order of operations, same results as kB (the parity tests run on both).
+#ifndef KCC_RING_AUX
+#define KCC_RING_AUX 0              // cache policy of the DMA loads: 0 default, 2 = nt
+#endif
+#ifndef KCC_RING_LK480
+#define KCC_RING_LK480 4
+#endif
+#ifndef KCC_RING_LK640
+#define KCC_RING_LK640 3
+#endif
+#ifndef KCC_RING_LK640A
+#define KCC_RING_LK640A 6           // single-plane kernels (PlanAlt<640>: 32 threads per line)
+#endif
+#ifndef KCC_RING_LK1280
+#define KCC_RING_LK1280 1
+#endif
+__host__ __device__ constexpr bool ring_two_plane(int mode) { return mode == B_MUL_INV || mode == B_FWD_MUL_INV || mode == B_SOLVE_INV; }
+__host__ __device__ constexpr bool ring_mode_ok(int mode) { return ring_two_plane(mode) || mode == B_FWD_ABS_INV; }
+__host__ __device__ constexpr int ring_lk(int n, int mode) {
+    return n == 480 ? KCC_RING_LK480 : n == 640 ? (ring_two_plane(mode) ? KCC_RING_LK640 : KCC_RING_LK640A) : n == 1280 ? KCC_RING_LK1280 : 0;
+}
+template <int N, int MODE> struct RCfg {
+    static constexpr bool ALT = !ring_two_plane(MODE);
+    using P = typename std::conditional<ALT, PlanAlt<N>, PlanFor<N>>::type;
+    static constexpr int T = P::T;
+    static constexpr int LK = ring_lk(N, MODE) > 0 ? ring_lk(N, MODE) : 1;
+    static constexpr int NTC = LK * T;                               // consumer threads
+    static constexpr int NTCW = (NTC + 63) / 64 * 64;                // ... rounded up to whole waves
+    static constexpr int NT = NTCW + 64;                             // + the loader wave (the last one)
+    static constexpr int EPITCH = ((P::EXT + 31 - (T % 32)) / 32) * 32 + (T % 32);
+    static constexpr int NBUF = ALT ? 1 : 2;                         // plane buffers per set
+    static constexpr int BUF = (LK * EPITCH + 1) / 2 * 2;            // cf2 per plane buffer (16-byte multiple)
+    // both directions' pass-twiddle tables live in LDS (copied once per workgroup): a consumer wave that loaded them from
+    // global memory would wait for the stores of its previous tile at the first twiddle it needs (loads and stores share one
+    // vmcnt on gfx950 and the compiler must assume they complete out of order: s_waitcnt vmcnt(0))
+    static constexpr int TWF = P::NP == 3 ? P::R2 * P::R1 + N : N, TWI = P::NP == 3 ? P::R2 * P::R3 + N : N;
+    static constexpr size_t TW_OFF = (size_t)2 * NBUF * BUF * sizeof(cf2);
+    static constexpr size_t RMAX_OFF = TW_OFF + (size_t)(TWF + TWI) * sizeof(cf2);
+    static constexpr size_t BYTES = RMAX_OFF + 16;                   // ... + the running maxima of the solve, double-buffered
+    static constexpr bool WLB = KCC_WAVE_LOCAL && ALT && (64 % T == 0);
+    static constexpr int CB = WLB ? 0 : (P::NP == 3 ? 3 : 1);        // workgroup barriers inside one fft_chain
+    // barriers a consumer executes per tile (the loader wave joins every one of them)
+    static constexpr int K = MODE == B_MUL_INV ? 2 + CB : MODE == B_FWD_ABS_INV ? 2 + 2 * CB + (WLB ? 0 : 1) : 3 + 2 * CB;
+    // 16-byte pieces per line of each input plane
+    static constexpr int PPR_FULL = N / 2, PPR_HALF = (N / 2 + 2) / 2;
+    static constexpr int WGPC = (int)(163840 / BYTES) < 1 ? 1 : (int)(163840 / BYTES);   // workgroups per CU by LDS
+    static constexpr int WPS = (WGPC * (NT / 64) + 3) / 4 > 8 ? 8 : (WGPC * (NT / 64) + 3) / 4;   // waves per SIMD that occupancy needs
+};
+
+// LDS-DMA of NROWS lines (PPR 16-byte pieces each, row_stride bytes apart in global memory) into lds_dst, piece i of the tile
+// at byte 16 i; lines >= nvalid repeat line nvalid - 1 (their results are never stored).  One wave.
+template <int PPR, int NROWS>
+__device__ __forceinline__ void ring_dma(const char* __restrict__ g0, size_t row_stride, int nvalid, char* lds_dst, int lane) {
+    constexpr int TOTAL = PPR * NROWS, ITERS = (TOTAL + 63) / 64;
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+        const int i = it * 64 + lane;
+        if (i < TOTAL) {
+            int row = i / PPR; const int p = i - row * PPR;
+            row = min(row, nvalid - 1);
+            __builtin_amdgcn_global_load_lds((glb_void*)(g0 + (size_t)row * row_stride + (size_t)p * 16), (lds_void*)(lds_dst + it * 1024), 16, 0, KCC_RING_AUX);
+        }
+    }
+}
+// (ablation builds only: a skipped chain must still execute its barriers -- the loader wave counts them)
+template <int CB> __device__ __forceinline__ void chain_barriers_only() {
+#pragma unroll
+    for (int b = 0; b < CB; ++b) __syncthreads();
+}
+template <int RR>
+__device__ __forceinline__ void load_lds(cf2 (&v)[RR], const cf2* p, int stride, bool ok) {
+    if (ok) {
+#pragma unroll
+        for (int q = 0; q < RR; ++q) v[q] = p[q * stride];
+    } else {
+        zero_fill(v);
+    }
+}
+
+template <int N, int MODE>
+__global__ __launch_bounds__((RCfg<N, MODE>::NT), (RCfg<N, MODE>::WPS)) void kBr(BArgs a, int n_items) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using C = RCfg<N, MODE>; using P = typename C::P; using DF = Dir<P, false>; using DI = Dir<P, true>;
+    static_assert(DF::RL == DI::RF && DF::ML == DI::MF && DI::RL == DF::RF, "direction layouts must chain");
+    constexpr int LK = C::LK, SET = C::NBUF * C::BUF;
+    cf2* lds = reinterpret_cast<cf2*>(smem);
+    float* s_rmax = reinterpret_cast<float*>(smem + C::RMAX_OFF);    // [set][2]
+    cf2* const twf = reinterpret_cast<cf2*>(smem + C::TW_OFF), * const twi = twf + C::TWF;
+    const int tpi = (a.hr + LK - 1) / LK;                             // tiles per item
+    const int total = tpi * n_items;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool noload = ABL(a, 1), nost = ABL(a, 2), nofft = ABL(a, 4);
+
+    if (wave == C::NTCW / 64) {
+        // ---------------------------------------------------------------- loader wave
+        const int lane = (int)threadIdx.x & 63;
+        auto issue = [&](int t, int set) {
+            int item = t / tpi; const int k0 = (t - item * tpi) * LK;
+            if (a.rev) item = n_items - 1 - item;
+            const int nvalid = min(LK, a.hr - k0);
+            char* dst = smem + (size_t)set * SET * sizeof(cf2);
+            const size_t row = (size_t)N * sizeof(cf2), off = (size_t)k0 * row;
+            if (noload) return;
+            if (MODE == B_SOLVE_INV) {
+                const char* src = reinterpret_cast<const char*>(a.src.p + (size_t)item * a.src_stride) + off;
+                if (a.zz_half) ring_dma<C::PPR_HALF, LK>(src, row, nvalid, dst, lane);
+                else ring_dma<C::PPR_FULL, LK>(src, row, nvalid, dst, lane);
+                ring_dma<C::PPR_FULL, LK>(src + a.in_plane_stride * sizeof(cf2), row, nvalid, dst + C::BUF * sizeof(cf2), lane);
+                // the running maxima of the item's two kernel planes (kA_inv kernel_fwd filed them as parts): folded HERE, by the
+                // wave whose vmcnt holds only loads, and handed over through LDS with the tile
+                const float m0 = parts_max(a.maxbuf + (size_t)(2 * item + 0) * KCC_MAXPARTS, a.n_parts[0], lane);
+                const float m1 = parts_max(a.maxbuf + (size_t)(2 * item + 1) * KCC_MAXPARTS, a.n_parts[1], lane);
+                if (lane == 0) { s_rmax[2 * set] = m0; s_rmax[2 * set + 1] = m1; }
+            } else if (MODE == B_FWD_ABS_INV) {
+                ring_dma<C::PPR_FULL, LK>(reinterpret_cast<const char*>(a.src.p + (size_t)item * a.src_stride) + off, row, nvalid, dst, lane);
+            } else {
+                const int xi = a.src_idx ? a.src_idx[item] : item, zi = a.z_idx ? a.z_idx[item] : item;
+                ring_dma<C::PPR_FULL, LK>(reinterpret_cast<const char*>(a.src.p + (size_t)xi * a.src_stride) + off, row, nvalid, dst, lane);
+                ring_dma<C::PPR_FULL, LK>(reinterpret_cast<const char*>(a.zsrc.p + (size_t)zi * a.z_stride) + off, row, nvalid, dst + C::BUF * sizeof(cf2), lane);
+            }
+        };
+        int t = (int)blockIdx.x, n = 0;
+        if (t < total) issue(t, 0);
+        for (; t < total; t += (int)gridDim.x, ++n) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // tile n has landed ...
+            asm volatile("s_barrier" ::: "memory");                   // ... and the consumers are done with the other set
+            if (t + (int)gridDim.x < total) issue(t + (int)gridDim.x, (n + 1) & 1);
+#pragma unroll
+            for (int b = 1; b < C::K; ++b) asm volatile("s_barrier" ::: "memory");
+        }
+        return;
+    }
+
+    // -------------------------------------------------------------------- consumer waves
+    const bool live = threadIdx.x < (unsigned)C::NTC;                 // (the last consumer wave may be partly idle)
+    const unsigned tid = threadIdx.x, lk = live ? tid / (unsigned)C::T : 0u, j = live ? tid - lk * C::T : (unsigned)C::T;
+    constexpr bool WLB = C::WLB;
+    for (int i = (int)tid; i < C::TWF; i += C::NTCW) twf[i] = a.tw_f[i];
+    for (int i = (int)tid; i < C::TWI; i += C::NTCW) twi[i] = a.tw_i[i];
+    int n = 0;
+    for (int t = (int)blockIdx.x; t < total; t += (int)gridDim.x, ++n) {
+        int item = t / tpi; const int k0 = (t - item * tpi) * LK;
+        if (a.rev) item = n_items - 1 - item;
+        const int k = k0 + (int)lk;
+        const bool valid0 = live && k < a.hr, vst = valid0 && !nost;
+        const size_t loff = (size_t)k * N + j;
+        cf2* const set = lds + (size_t)(n & 1) * SET;
+        cf2* const b0 = set, * const b1 = set + (C::NBUF - 1) * C::BUF;
+        cf2* const ex1[1] = { b0 + lk * C::EPITCH };
+        cf2* const ex2[2] = { b0 + lk * C::EPITCH, b1 + lk * C::EPITCH };
+        __syncthreads();                                              // B0: the tile's lines are in LDS
+        if (MODE == B_FWD_ABS_INV) {
+            cf2 vin[1][DF::RF], f[1][DF::RL], o[1][DI::RL];
+            load_lds(vin[0], b0 + lk * N + j, DF::MF, j < DF::MF);
+            __syncthreads();                                          // B1: staged lines consumed before the exchange overwrites them
+            if (!nofft) fft_chain<P, false, 1, WLB>(vin, f, j, ex1, twf); else chain_barriers_only<C::CB>();
+            if (vst && j < DF::ML)
+                store_strided(f[0], a.dst + (size_t)(a.dst_slot ? a.dst_slot[item] : item) * a.dst_stride + loff, DF::ML);
+#pragma unroll
+            for (int q = 0; q < DF::RL; ++q) f[0][q] = mk2(sqrtf(f[0][q].x * f[0][q].x + f[0][q].y * f[0][q].y), 0.f);
+            line_sync<WLB>();
+            if (!nofft) fft_chain<P, true, 1, WLB>(f, o, j, ex1, twi); else chain_barriers_only<C::CB>();
+            if (vst && j < DI::ML) {
+                cf2* d2 = a.dst2 + (size_t)item * a.dst2_stride + loff;
+                if (a.zz_half > 0) {
+#pragma unroll
+                    for (int q = 0; q < DI::RL; ++q) if ((int)j + q * DI::ML < a.zz_half) d2[q * DI::ML] = o[0][q];
+                } else {
+                    store_strided(o[0], d2, DI::ML);
+                }
+            }
+        } else if (MODE == B_MUL_INV || MODE == B_FWD_MUL_INV) {
+            cf2 pr[2][DI::RF], o[2][DI::RL];
+            if (MODE == B_FWD_MUL_INV) {
+                cf2 vin[1][DF::RF], x[1][DF::RL];
+                load_lds(vin[0], b0 + lk * N + j, DF::MF, j < DF::MF);
+                __syncthreads();                                      // B1
+                if (!nofft) fft_chain<P, false, 1, WLB>(vin, x, j, ex1, twf); else chain_barriers_only<C::CB>();
+                if (a.dst2 && vst && j < DF::ML)
+                    store_strided(x[0], a.dst2 + (size_t)(a.dst2_slot ? a.dst2_slot[item] : item) * a.dst2_stride + loff, DF::ML);
+                // the key line is picked up only now (plane buffer 1 is untouched by the single-plane chain): no registers held across it
+                load_lds(pr[0], b1 + lk * N + j, DI::MF, j < DI::MF);
+#pragma unroll
+                for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(x[0][q], pr[0][q]);
+            } else {
+                load_lds(pr[1], b0 + lk * N + j, DI::MF, j < DI::MF);
+                load_lds(pr[0], b1 + lk * N + j, DI::MF, j < DI::MF);
+#pragma unroll
+                for (int q = 0; q < DI::RF; ++q) pr[1][q] = cmulc(pr[1][q], pr[0][q]);
+            }
+#pragma unroll
+            for (int q = 0; q < DI::RF; ++q) pr[0][q] = mk2(pr[0][q].x * pr[0][q].x + pr[0][q].y * pr[0][q].y, 0.f);
+            __syncthreads();                                          // B2
+            if (!nofft) fft_chain<P, true, 2>(pr, o, j, ex2, twi); else chain_barriers_only<C::CB>();
+            if (vst && j < DI::ML) {
+                cf2* d = a.dst + (size_t)item * a.dst_stride + loff;
+                if (a.zz_half > 0) {
+#pragma unroll
+                    for (int q = 0; q < DI::RL; ++q) if ((int)j + q * DI::ML < a.zz_half) d[q * DI::ML] = o[0][q];
+                } else {
+                    store_strided(o[0], d, DI::ML);
+                }
+                store_strided(o[1], d + a.out_plane_stride, DI::ML);
+            }
+        } else {
+            // B_SOLVE_INV
+            cf2 vin[2][DF::RF], kk[2][DF::RL], g[1][DI::RF], o[1][DI::RL];
+            if (a.zz_half) {
+                if (j < DF::MF) {
+                    const cf2* row = b0 + lk * (2 * C::PPR_HALF);
+#pragma unroll
+                    for (int q = 0; q < DF::RF; ++q) {
+                        const int x = (int)j + q * DF::MF;
+                        const cf2 v = row[x <= N / 2 ? x : N - x];
+                        vin[0][q] = mk2(v.x, x <= N / 2 ? v.y : -v.y);
+                    }
+                } else {
+                    zero_fill(vin[0]);
+                }
+            } else {
+                load_lds(vin[0], b0 + lk * N + j, DF::MF, j < DF::MF);
+            }
+            load_lds(vin[1], b1 + lk * N + j, DF::MF, j < DF::MF);
+            __syncthreads();                                          // B1
+            if (!nofft) fft_chain<P, false, 2>(vin, kk, j, ex2, twf); else chain_barriers_only<C::CB>();
+            const float rzz = 1.0f / s_rmax[2 * (n & 1)], rxz = 1.0f / s_rmax[2 * (n & 1) + 1];   // (the loader wave filed them with the tile)
+            static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
+            const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
+#pragma unroll
+            for (int q = 0; q < DF::RL; ++q) {
+                const cf2 den = mk2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
+                const cf2 num = mk2(kk[1][q].x * rxz, kk[1][q].y * rxz);
+                const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
+                const cf2 gg = cmulc(num, den);
+                g[0][q] = mk2(gg.x * inv, gg.y * inv);
+            }
+            if (!(valid0 && j < DF::ML)) zero_fill(g[0]);
+            __syncthreads();                                          // B2
+            if (!nofft) fft_chain<P, true, 1, WLB>(g, o, j, ex1, twi); else chain_barriers_only<C::CB>();
+            if (vst && j < DI::ML) store_strided(o[0], a.dst + (size_t)item * a.dst_stride + loff, DI::ML);
+        }
+    }
+}
+
+// $NIK_RING: bit mask of the B kernels that run in ring form -- 1 fwd_abs_inv, 2 mul_inv / fwd_mul_inv, 4 solve_inv; batches
+// too small to give every resident workgroup two tiles keep the one-tile-per-workgroup kernels
+#ifndef KCC_RING_DEFAULT
+#define KCC_RING_DEFAULT 0
+#endif
+static int ring_mask() { static const int m = getenv("NIK_RING") ? atoi(getenv("NIK_RING")) : KCC_RING_DEFAULT; return m; }
+static int ring_wgpc() { static const int m = getenv("NIK_RING_WGPC") ? atoi(getenv("NIK_RING_WGPC")) : 0; return m; }
+template <int N, int MODE> static bool launchBr_t(hipStream_t s, int n_items, const BArgs& a_in) {
+    if constexpr (ring_mode_ok(MODE) && ring_lk(N, MODE) > 0) {
+        using C = RCfg<N, MODE>;
+        const int bit = MODE == B_FWD_ABS_INV ? 1 : MODE == B_SOLVE_INV ? 4 : 2;
+        if (!(ring_mask() & bit)) return false;
+        BArgs a = a_in;
+        if (C::ALT) { a.tw_f = a.twA_f; a.tw_i = a.twA_i; }
+        static const int cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256; return p.multiProcessorCount; }();
+        const int wgpc = ring_wgpc() > 0 ? std::min(ring_wgpc(), C::WGPC) : C::WGPC;
+        static const bool force = getenv("NIK_RING_FORCE") && atoi(getenv("NIK_RING_FORCE"));   // tests: ring form at every batch size
+        const int total = ((a.hr + C::LK - 1) / C::LK) * n_items;
+        int slots = wgpc * cus;
+        if (total < 2 * slots) { if (!force) return false; slots = std::max(1, std::min(slots, (total + 1) / 2)); }
+        static const bool big_lds = (C::BYTES > 65536) &&
+            (hipFuncSetAttribute(reinterpret_cast<const void*>(&kBr<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
+        (void)big_lds;
+        hipLaunchKernelGGL((kBr<N, MODE>), dim3(slots), dim3(C::NT), C::BYTES, s, a, n_items);
+        return true;
+    } else {
+        return false;
+    }
+}
+
 template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a_in) {
+    if (launchBr_t<N, MODE>(s, n_items, a_in)) return;
     BArgs a = a_in;
     if (BCfg<N, MODE>::ALT) { a.tw_f = a.twA_f; a.tw_i = a.twA_i; }
     constexpr int LK = BCfg<N, MODE>::LK;
