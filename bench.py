@@ -344,7 +344,7 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
             _, _, _, secs_1 = ko.track_pairs(ocfg, keys_u8[:n1], curs_u8[:n1], True, faithful=False, nthreads=1)
             _, _, _, secs_1f = ko.track_pairs(ocfg, keys_u8[:n1], curs_u8[:n1], True, faithful=True, nthreads=1)
             cpu = dict(value=round(ns / secs_all, 2), unit="frame-pairs/s", cores=nthr, kind="port",
-                       sample="%d unique pairs of the same 640x480 workload, lean mode, OpenMP over pairs" % ns,
+                       sample="%d unique pairs of the same %dx%d workload, lean mode, OpenMP over pairs" % (ns, W, H),
                        value_1thread=round(n1 / secs_1, 3), value_1thread_reference_faithful=round(n1 / secs_1f, 3),
                        host_cpus=ncores, gpu_results_match=bool(parity_ok), pairs_compared=ns)
         bpp = algorithmic_bytes(H, W, PD, PC)

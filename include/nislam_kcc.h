@@ -81,9 +81,12 @@ void nik_destroy(nik_ctx* ctx);
 const char* nik_last_error(const nik_ctx* ctx);      /* ctx may be NULL: last create() error */
 /* geometry queries (H, W, PD, PC, max_batch, max_frames) */
 int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
-/* 1 if the context runs the any-size kernel family (kcc_generic.hip: geometries outside the tiled kernels' instantiated set --
- * half-rows {30,60,120,224,240,360,600}, lines {80,160,320,448,480,640,1280,1600}, W and PC multiples of 16, aspect within
- * 2:1 -- or $NIK_GENERIC=1), 0 if it runs the tiled kernels.  Same results either way; the any-size family is slower. */
+/* Which plane families of the context run the any-size kernel family (kcc_generic.hip): a MASK -- bit 0 (1) the image family
+ * (H x W), bit 1 (2) the polar family (PD x PC); 0 = both on the tiled kernels, 3 = both on the any-size kernels.  (Test it
+ * with `!= 0` or per bit, not `== 1`.)  A family is any-size when its geometry is outside the tiled kernels' instantiated set --
+ * half-rows {30,60,120,224,240,256,360,376,600}, lines {80,160,320,448,480,512,640,752,1280,1600}, W and PC multiples of 16,
+ * aspect within 2:1 -- or when $NIK_GENERIC forces it (1 both, 2 polar only, 4 image only).  Same results either way; the
+ * any-size family is slower. */
 int  nik_is_generic(const nik_ctx* ctx);
 /* first of the context's streams (a hipStream_t, returned as void*) */
 void* nik_stream(const nik_ctx* ctx);
@@ -134,12 +137,15 @@ int nik_intermedium_f32(nik_ctx* ctx, const float* image_colmajor, nik_frame dst
  *   nik_upload_fence(ctx, ticket)        every compute lane waits ON THE DEVICE for that upload (call it before the *_dev
  *                                        entry point that reads d_dst; uploads enqueued later do not delay that work)
  *   nik_upload_wait(ctx)                 host-side: the source buffers of all uploads so far may be reused
+ *   nik_upload_after_compute(ctx)        the upload stream waits ON THE DEVICE for everything enqueued on the compute lanes so
+ *                                        far (call it before an upload that overwrites a device buffer earlier *_dev calls read)
  * A source in pinned memory (hipHostMalloc / hipHostRegister, e.g. a camera driver's DMA ring) is read by the copy engine
  * directly; a pageable one is staged through two pinned buffers of the context.  At most four uploads may be un-fenced.
  * nik_dev_malloc / nik_dev_free: device buffers on the context's GPU for callers that do not link the HIP runtime. */
 int nik_upload_u8_async(nik_ctx* ctx, int n, const uint8_t* gray, int stride, size_t frame_stride, uint8_t* d_dst);
 int nik_upload_fence(nik_ctx* ctx, int ticket);
 int nik_upload_wait(nik_ctx* ctx);
+int nik_upload_after_compute(nik_ctx* ctx);
 int nik_dev_malloc(nik_ctx* ctx, size_t bytes, void** out);
 int nik_dev_free(nik_ctx* ctx, void* p);
 /* batched, device-resident inputs: n u8 images [n][H][W] (row-major, tightly packed) already in HBM. */

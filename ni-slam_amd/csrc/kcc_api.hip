@@ -122,7 +122,7 @@ struct nik_ctx {
     std::vector<Lane> lanes; int active_lanes = 1;
     uint8_t* d_u8 = nullptr;             // staging for host u8 input (one image)
     // host frames -> device on the context's own upload stream (nik_upload_u8_async): never on a compute lane
-    hipStream_t up_stream = nullptr; hipEvent_t up_ev[4] = { nullptr, nullptr, nullptr, nullptr }; unsigned up_seq = 0; int up_fenced = -1;
+    hipStream_t up_stream = nullptr; hipEvent_t up_ev[4] = { nullptr, nullptr, nullptr, nullptr }; unsigned up_seq = 0; int up_fenced = -1; hipEvent_t up_after_ev = nullptr;
     uint8_t* up_pin[2] = { nullptr, nullptr }; hipEvent_t up_pin_ev[2] = { nullptr, nullptr }; bool up_pin_busy[2] = { false, false };
     size_t up_pin_bytes = 0; int up_pin_next = 0;
     float* d_scratch = nullptr;          // debug / import-export staging
@@ -789,7 +789,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     // BORDER_WRAP).  Every other geometry the reference accepts (correlation_flow.cc:53-77: any size with even rows) runs the
     // any-size family (kcc_generic.hip): slower, same results.  $NIK_GENERIC=1 forces it (tests compare the two families).
     // The choice is per plane family: a 640 x 480 camera with a 720 x 64 polar plane keeps the tiled image kernels.
-    const int force = getenv("NIK_GENERIC") ? atoi(getenv("NIK_GENERIC")) : 0;      // bit 0: image family, bit 1: polar family; 1 = both (tests)
+    const int force = getenv("NIK_GENERIC") ? atoi(getenv("NIK_GENERIC")) : 0;      // 1 = both families, 2 = polar family only, 4 = image family only (tests)
     const bool gen_img = !(fft_half_supported(H / 2) && fft_line_supported(W) && W % 16 == 0 && !(H / 2 + 2 > W || W / 2 + 2 > H)) || force == 1 || (force & 4);
     bool gen_pol = !(fft_half_supported(PD / 2) && fft_line_supported(PC) && PC % 16 == 0) || force == 1 || (force & 2);
     const bool generic = gen_img || gen_pol;
@@ -814,7 +814,12 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
     // the tiled polar gather stages annulus segments of THIS image geometry in LDS: an image size whose segments do not fit
     // sends the polar family to the any-size kernels as well
-    if (!c->gen_pol && build_polar_table(c)) { c->gen_pol = true; c->generic = true; c->err.clear(); }
+    // (only THAT outcome -- NIK_ERR_UNSUPPORTED_SIZE -- falls back; an allocation or copy error of the table upload is an error)
+    if (!c->gen_pol) {
+        const int prc = build_polar_table(c);
+        if (prc == NIK_ERR_UNSUPPORTED_SIZE) { c->gen_pol = true; c->generic = true; c->err.clear(); }
+        else if (prc) return bail(prc);
+    }
     if (c->generic && (rc = generic_init(c))) return bail(rc);
     c->partial_stride = std::max(c->gen_img ? g_argmax_blocks(H, W) : argmax_blocks(c->img.g), c->gen_pol ? g_argmax_blocks(PD, PC) : argmax_blocks(c->pol.g));
     // column pitch: >= H + 4 (wrap rows), a multiple of 32 floats (columns start on 128-byte lines) and an ODD multiple
@@ -875,6 +880,7 @@ void nik_destroy(nik_ctx* c) {
     if (c->up_stream) { (void)hipStreamSynchronize(c->up_stream); (void)hipStreamDestroy(c->up_stream); }
     for (hipEvent_t e : c->up_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->up_pin_ev) if (e) (void)hipEventDestroy(e);
+    if (c->up_after_ev) (void)hipEventDestroy(c->up_after_ev);
     for (uint8_t* q : c->up_pin) if (q) (void)hipHostFree(q);
     for (float2* q : c->g_tw) (void)hipFree(q);
     (void)hipFree(c->g_polar_map);
@@ -1108,6 +1114,7 @@ int nik_upload_u8_async(nik_ctx* c, int n, const uint8_t* gray, int stride, size
 int nik_upload_fence(nik_ctx* c, int ticket) {
     if (!c || ticket < 0 || !c->up_stream) return fail(c, NIK_ERR_INVALID_ARG, "no such upload");
     if ((unsigned)ticket + 4 < (c->up_seq & 0x3FFFFFFFu) ) return fail(c, NIK_ERR_INVALID_ARG, "upload ticket %d is older than the four tracked uploads", ticket);
+    if ((unsigned)ticket >= (c->up_seq & 0x3FFFFFFFu)) return fail(c, NIK_ERR_INVALID_ARG, "upload ticket %d was never issued", ticket);   // (its event is unrecorded or stale)
     // (only the lanes that exist: a stream that is merely created takes a hardware queue from the ones that work; a lane created
     // later waits for the latest fenced upload when it is created -- ensure_lanes)
     for (int li = 0; li < c->active_lanes; ++li)
@@ -1125,6 +1132,21 @@ int nik_dev_malloc(nik_ctx* c, size_t bytes, void** out) {
 int nik_dev_free(nik_ctx* c, void* p) {
     if (!c) return NIK_ERR_INVALID_ARG;
     if (p) { HIP_TRY(c, hipSetDevice(c->device)); HIP_TRY(c, hipFree(p)); }
+    return NIK_OK;
+}
+// the upload stream waits (on the device) for everything enqueued on the compute lanes so far: an upload enqueued next may
+// overwrite a device buffer those calls still read (the tracker's upload ring reusing a window buffer)
+int nik_upload_after_compute(nik_ctx* c) {
+    if (!c) return NIK_ERR_INVALID_ARG;
+    if (!c->up_stream) return NIK_OK;                       // (nothing uploaded yet: the first upload creates the stream)
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int li = 0; li < c->active_lanes; ++li) {
+        Lane& L = c->lanes[li];
+        if (!L.stream) continue;
+        if (!c->up_after_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->up_after_ev, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->up_after_ev, L.stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->up_stream, c->up_after_ev, 0));
+    }
     return NIK_OK;
 }
 // host-side wait: the SOURCE buffers of every upload enqueued so far may be reused
@@ -1280,6 +1302,10 @@ static int pose_call(nik_ctx* c, int n, const uint8_t* d_gray, const nik_frame* 
         if (upper->last_pose_n != n || upper->last_pose_nhyp != 1 || upper->last_pose_nc != nc || lanes_for(upper, n) != nl)
             return fail(c, NIK_ERR_NOT_READY, "chained call: the upper level's latest pose call does not match (n %d/%d, hypotheses %d, chunks %d/%d)",
                         upper->last_pose_n, n, upper->last_pose_nhyp, upper->last_pose_nc, nc);
+        // chunk ci of the upper call ran on lane (lane_base + ci) % LN when its lanes rotate (nik_set_lane_rotation): the windows
+        // are read from upper->lanes[ci % nl], which is that lane only without rotation
+        if (upper->lane_rot && upper->active_lanes > 1)
+            return fail(c, NIK_ERR_NOT_READY, "chained call: the upper level rotates its lanes (nik_set_lane_rotation); its results cannot be chained");
     }
     if (c->want_stats && c->stats_parts + nc > KCC_STATS_PARTS) return fail(c, NIK_ERR_CAPACITY, "residual statistics: more than %d chunks in one call", (int)KCC_STATS_PARTS);
     c->last_pose_n = n; c->last_pose_nhyp = not_large_rotation ? 1 : 2; c->last_pose_nc = nc;

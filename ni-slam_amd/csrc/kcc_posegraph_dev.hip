@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_pg_pcg(int n_free, const int* __restric
     double rz = block_sum(precond(), red);
     for (int i = tid; i < dim; i += 256) p[i] = z[i];
     __syncthreads();
-    int it = 0, code = 0;
+    int it = 0, code = 0, done = 0;
     for (; it < max_iter; ++it) {
         // Ap = (H + diag(damp)) p
         double a = 0;
@@ -190,13 +190,13 @@ __global__ __launch_bounds__(256) void k_pg_pcg(int n_free, const int* __restric
         for (int i = tid; i < dim; i += 256) { x[i] += alpha * p[i]; const double v = r[i] - alpha * Ap[i]; r[i] = v; rn += v * v; }
         __syncthreads();
         rn = block_sum(rn, red);
-        if (rn <= 1e-24 * bnorm) { ++it; break; }
+        if (rn <= 1e-24 * bnorm) { ++it; done = 1; break; }
         const double rz2 = block_sum(precond(), red);
         const double beta = rz2 / rz; rz = rz2;
         for (int i = tid; i < dim; i += 256) p[i] = z[i] + beta * p[i];
         __syncthreads();
     }
-    if (tid == 0) { status[0] = code; status[1] = it; }
+    if (tid == 0) { status[0] = code ? code : (done ? 0 : 2); status[1] = it; }
 }
 
 }  // namespace
@@ -314,23 +314,28 @@ int dev_linearize(DevProblem* p, const double* x, double* cost, double* r, doubl
 // (J^T J + diag(damp)) step = -g for the point of the latest FULL linearisation (its blocks are still on the device; cost-only
 // evaluations in between leave them alone).  damp, step: host, dim doubles.  Returns 0, 1 (not positive definite: the caller
 // shrinks the trust region, as after a failed host solve) or a negative hipError_t.
+// (dev_solve's contract is "negative on a HIP error": PG_TRY returns the positive hipError_t, which optimize() would read as
+// "not positive definite" and answer by shrinking the trust region until NIK_PG_FAILURE -- ADVICE r4)
+#define PG_TRYN(p, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (p)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return -(int)e_; } } while (0)
 int dev_solve(DevProblem* p, const double* damp, double* step, int* iterations) {
     if (p->n_free == 0) return 0;
-    PG_TRY(p, hipSetDevice(p->device));
-    PG_TRY(p, hipStreamSynchronize(p->stream));               // (h_pin may still feed an earlier upload)
+    PG_TRYN(p, hipSetDevice(p->device));
+    PG_TRYN(p, hipStreamSynchronize(p->stream));               // (h_pin may still feed an earlier upload)
     const size_t dim = 3 * (size_t)p->n_free;
     std::copy(damp, damp + dim, p->h_pin);
-    PG_TRY(p, hipMemcpyAsync(p->d_damp, p->h_pin, sizeof(double) * dim, hipMemcpyHostToDevice, p->stream));
+    PG_TRYN(p, hipMemcpyAsync(p->d_damp, p->h_pin, sizeof(double) * dim, hipMemcpyHostToDevice, p->stream));
     hipLaunchKernelGGL(k_pg_pcg, dim3(1), dim3(256), 0, p->stream, p->n_free, p->d_first, p->d_inc, p->d_edges, p->d_diag, p->d_off, p->d_g, p->d_damp,
                        p->d_work, p->d_minv, (int)(20 * dim), p->d_status);
-    PG_TRY(p, hipGetLastError());
+    PG_TRYN(p, hipGetLastError());
     int st[2] = { 0, 0 };
-    PG_TRY(p, hipMemcpyAsync(p->h_pin, p->d_work, sizeof(double) * dim, hipMemcpyDeviceToHost, p->stream));
-    PG_TRY(p, hipMemcpyAsync(st, p->d_status, sizeof(st), hipMemcpyDeviceToHost, p->stream));
-    PG_TRY(p, hipStreamSynchronize(p->stream));
+    PG_TRYN(p, hipMemcpyAsync(p->h_pin, p->d_work, sizeof(double) * dim, hipMemcpyDeviceToHost, p->stream));
+    PG_TRYN(p, hipMemcpyAsync(st, p->d_status, sizeof(st), hipMemcpyDeviceToHost, p->stream));
+    PG_TRYN(p, hipStreamSynchronize(p->stream));
     std::copy(p->h_pin, p->h_pin + dim, step);
     if (iterations) *iterations = st[1];
-    return st[0] ? 1 : 0;
+    // st[0]: 0 converged, 1 not positive definite, 2 iteration limit reached without convergence (the step is still the best
+    // iterate: the trust-region test of the caller accepts or rejects it on its merits)
+    return st[0] == 1 ? 1 : 0;
 }
 
 int dev_cost_async(DevProblem* p, const double* x, double** d_cost, void** stream) {

@@ -619,18 +619,34 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
     auto count = [&](int k) { return std::min(win, n - k * win); };
     auto upload = [&](int k) { return nik_upload_u8_async(t->ctx, count(k), gray + (size_t)k * win * frame_stride, stride, frame_stride, t->d_up[k % 3]); };
     std::vector<int> tk(nw + 2, -1);
-    if ((tk[0] = upload(0)) < 0) return tk[0];
-    if (nw > 1 && (tk[1] = upload(1)) < 0) return tk[1];
-    if ((rc = nik_upload_fence(t->ctx, tk[0]))) return rc;
+    // on an error: no prefetched window stays behind (its slots go back, flights that name them are waited for and dropped, and
+    // the `!pre.empty()` guard above does not lock the tracker out for good), and no upload of this call is still in flight
+    auto bail = [&](int code) {
+        (void)t->drop_flights();
+        for (auto it = t->pre.rbegin(); it != t->pre.rend(); ++it)
+            for (int i = it->n - 1; i >= 0; --i) t->free_slots.push_back(it->slots[i]);
+        t->pre.clear();
+        t->known.resize(std::min<size_t>(t->known.size(), (size_t)std::max(0, t->frame_id - t->known0)));
+        (void)nik_upload_wait(t->ctx);
+        return code;
+    };
+    if ((tk[0] = upload(0)) < 0) return bail(tk[0]);
+    if (nw > 1 && (tk[1] = upload(1)) < 0) return bail(tk[1]);
+    if ((rc = nik_upload_fence(t->ctx, tk[0]))) return bail(rc);
     for (int k = 0; k < nw; ++k) {
         if (k + 1 < nw) {
             // window k+1: its upload was enqueued a whole window ago -- wait for it on the device, start its spectra; window k+2:
-            // start its upload (into the buffer of window k-1, whose push has returned)
-            if ((rc = nik_upload_fence(t->ctx, tk[k + 1]))) return rc;
-            if (k + 2 < nw && (tk[k + 2] = upload(k + 2)) < 0) return tk[k + 2];
-            if ((rc = nik_tracker_prefetch_dev(t, count(k + 1), t->d_up[(k + 1) % 3]))) return rc;
+            // start its upload (into the buffer of window k-1, whose push has returned).  That buffer's last READER is the
+            // ComputeIntermedium batch of window k-1 on the compute lanes (enqueued by prefetch / push, possibly still pending
+            // when max_batch is small and a window holds no waited registration): the upload stream waits for the lanes first.
+            if ((rc = nik_upload_fence(t->ctx, tk[k + 1]))) return bail(rc);
+            if (k + 2 < nw) {
+                if (k >= 1 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
+                if ((tk[k + 2] = upload(k + 2)) < 0) return bail(tk[k + 2]);
+            }
+            if ((rc = nik_tracker_prefetch_dev(t, count(k + 1), t->d_up[(k + 1) % 3]))) return bail(rc);
         }
-        if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return rc;
+        if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return bail(rc);
     }
     return nik_upload_wait(t->ctx);
 }

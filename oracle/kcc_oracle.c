@@ -19,6 +19,29 @@
 #include <omp.h>
 #endif
 
+
+/* ------------------------------------------------------------------ */
+/* per-thread stack arena for the plane-sized temporaries              */
+/* ------------------------------------------------------------------ */
+/* The reference allocates its Eigen temporaries per call; so did this port -- and on a 256-thread host the allocator
+ * (mmap / page faults / arena trimming behind malloc) stopped the OpenMP batch driver from scaling beyond 16 threads
+ * (profiles/r04_cpu_scale.txt).  ora_track_pairs gives every thread ONE block up front; the temporaries of the hot path
+ * are carved from it stack-wise (every function frees what it allocated before it returns).  Outside ora_track_pairs no
+ * arena is reserved and tmp_alloc IS malloc.  Timing infrastructure only: no arithmetic changes. */
+static __thread char* t_arena = NULL; static __thread size_t t_cap = 0, t_top = 0;
+static void* tmp_alloc(size_t n) {
+    n = (n + 63) & ~(size_t)63;
+    if (t_arena && t_top + n <= t_cap) { void* p = t_arena + t_top; t_top += n; return p; }
+    return malloc(n);
+}
+static void tmp_free(void* p) {
+    if (!p) return;
+    if (t_arena && (char*)p >= t_arena && (char*)p < t_arena + t_cap) { const size_t off = (size_t)((char*)p - t_arena); if (off < t_top) t_top = off; return; }
+    free(p);
+}
+static void tmp_reserve(size_t bytes) { t_arena = (char*)malloc(bytes); t_cap = t_arena ? bytes : 0; t_top = 0; if (t_arena) memset(t_arena, 0, bytes); }
+static void tmp_release(void) { free(t_arena); t_arena = NULL; t_cap = t_top = 0; }
+
 /* ------------------------------------------------------------------ */
 /* float32 mixed-radix FFT (stands in for FFTW3f, which is un-vendored) */
 /* ------------------------------------------------------------------ */
@@ -86,7 +109,7 @@ static void stockham_pass(const ora_cf32* in, ora_cf32* out, int n, int r, int N
     const int rstep = n / r;              /* W_r^t = tw[t*rstep] */
     ora_cf32 vs[64], ys[64];
     ora_cf32* v = vs; ora_cf32* y = ys;
-    if (r > 64) { v = (ora_cf32*)malloc(sizeof(ora_cf32) * 2 * (size_t)r); y = v + r; }   /* a prime factor beyond 61 (e.g. 158 = 2 x 79) */
+    if (r > 64) { v = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * 2 * (size_t)r); y = v + r; }   /* a prime factor beyond 61 (e.g. 158 = 2 x 79) */
     for (int j = 0; j < m; ++j) {
         const int k = j % Ns;
         for (int q = 0; q < r; ++q) {
@@ -122,7 +145,7 @@ static void stockham_pass(const ora_cf32* in, ora_cf32* out, int n, int r, int N
         const int j0 = (j / Ns) * Ns * r + k;
         for (int q = 0; q < r; ++q) out[j0 + q * Ns] = y[q];
     }
-    if (v != vs) free(v);
+    if (v != vs) tmp_free(v);
 }
 
 /* In-place unnormalised complex FFT of contiguous data[n]; work[n] scratch. */
@@ -179,7 +202,7 @@ void ora_fft(ora_ctx* ctx, const float* x, int rows, int cols, ora_cf32* xf) {
     const ora_plan* pn = get_plan(ctx, rows);
     const ora_plan* pc = get_plan(ctx, cols);
     int mx = rows > cols ? rows : cols;
-    ora_cf32* z = (ora_cf32*)malloc(sizeof(ora_cf32) * (size_t)mx * 2);
+    ora_cf32* z = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * (size_t)mx * 2);
     ora_cf32* work = z + mx;
     for (int c = 0; c < cols; ++c) rfft_line(ph, pn, x + (size_t)c * rows, xf + (size_t)c * hr, z, work);
     for (int k = 0; k < hr; ++k) {
@@ -187,7 +210,7 @@ void ora_fft(ora_ctx* ctx, const float* x, int rows, int cols, ora_cf32* xf) {
         cfft(pc, z, work, 0);
         for (int c = 0; c < cols; ++c) xf[(size_t)c * hr + k] = z[c];
     }
-    free(z);
+    tmp_free(z);
 }
 
 /* CorrelationFlow::IFFT  correlation_flow.cc:65-77: c2r then x / x.size(). Requires even rows. */
@@ -197,9 +220,9 @@ void ora_ifft(ora_ctx* ctx, const ora_cf32* xf, int hrows, int cols, float* x) {
     const ora_plan* pn = get_plan(ctx, rows);
     const ora_plan* pc = get_plan(ctx, cols);
     int mx = rows > cols ? rows : cols;
-    ora_cf32* cxf = (ora_cf32*)malloc(sizeof(ora_cf32) * (size_t)hr * cols);   /* :68 copy */
+    ora_cf32* cxf = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * (size_t)hr * cols);   /* :68 copy */
     memcpy(cxf, xf, sizeof(ora_cf32) * (size_t)hr * cols);
-    ora_cf32* z = (ora_cf32*)malloc(sizeof(ora_cf32) * (size_t)mx * 2);
+    ora_cf32* z = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * (size_t)mx * 2);
     ora_cf32* work = z + mx;
     for (int k = 0; k < hr; ++k) {
         for (int c = 0; c < cols; ++c) z[c] = cxf[(size_t)c * hr + k];
@@ -209,7 +232,7 @@ void ora_ifft(ora_ctx* ctx, const ora_cf32* xf, int hrows, int cols, float* x) {
     for (int c = 0; c < cols; ++c) irfft_line(ph, pn, cxf + (size_t)c * hr, x + (size_t)c * rows, z, work);
     const float size = (float)((long)rows * cols);                              /* :76 x/x.size() */
     for (long i = 0; i < (long)rows * cols; ++i) x[i] = x[i] / size;
-    free(z); free(cxf);
+    tmp_free(z); tmp_free(cxf);
 }
 
 /* ------------------------------------------------------------------ */
@@ -312,7 +335,7 @@ static void warp_affine_wrap(const float* x, int rows, int cols, const double Mi
     double b2 = -M[3] * M[2] - M[4] * M[5];
     M[2] = b1; M[5] = b2;
     const int round_delta = AB_SCALE / INTER_TAB_SIZE / 2;
-    int* adelta = (int*)malloc(sizeof(int) * (size_t)cols * 2);
+    int* adelta = (int*)tmp_alloc(sizeof(int) * (size_t)cols * 2);
     int* bdelta = adelta + cols;
     for (int c = 0; c < cols; ++c) {
         adelta[c] = cv_round_d(M[0] * c * AB_SCALE);
@@ -329,7 +352,7 @@ static void warp_affine_wrap(const float* x, int rows, int cols, const double Mi
                 X & (INTER_TAB_SIZE - 1), Y & (INTER_TAB_SIZE - 1), BORDER_WRAP_);
         }
     }
-    free(adelta);
+    tmp_free(adelta);
 }
 
 /* cv::getRotationMatrix2D(center (Point2f), angle [deg], scale = 1) */
@@ -350,10 +373,10 @@ void ora_rotate(const float* x, int rows, int cols, float degree, float* out) {
 /* WarpArray  utils.cc:163-171 (only reached by the dead `rectify` of correlation_flow.cc:141) */
 void ora_warp(const float* x, int rows, int cols, float tx, float ty, float degree, float* out) {
     const double m[6] = { 1, 0, (double)tx, 0, 1, (double)ty };  /* CV_32F matrix converted to CV_64F */
-    float* tmp = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    float* tmp = (float*)tmp_alloc(sizeof(float) * (size_t)rows * cols);
     warp_affine_wrap(x, rows, cols, m, tmp);
     ora_rotate(tmp, rows, cols, degree, out);
-    free(tmp);
+    tmp_free(tmp);
 }
 
 /* NormalizeDegree  utils.cc:173-175 */
@@ -433,19 +456,19 @@ void ora_intermedium(ora_ctx* ctx, const float* image, ora_cf32* fft_result, ora
     const int H = ctx->H, W = ctx->W, hr = H / 2 + 1;
     const size_t n = (size_t)H * W, nc = (size_t)hr * W;
     ora_fft(ctx, image, H, W, fft_result);                                  /* :91 */
-    ora_cf32* mag = (ora_cf32*)malloc(sizeof(ora_cf32) * nc);
+    ora_cf32* mag = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * nc);
     for (size_t i = 0; i < nc; ++i) {                                       /* :92 fft_result.abs() */
         mag[i].re = hypotf(fft_result[i].re, fft_result[i].im); mag[i].im = 0.f;
     }
-    float* power = (float*)malloc(sizeof(float) * n * 3);
+    float* power = (float*)tmp_alloc(sizeof(float) * n * 3);
     float* high = power + n; float* shifted = high + n;
     ora_ifft(ctx, mag, hr, W, power);
     ora_remove_zero(power, H, W, high);                                     /* :93 */
     ora_fftshift(high, H, W, shifted);                                      /* :94 */
-    float* pol = (float*)malloc(sizeof(float) * (size_t)ctx->PD * ctx->PC);
+    float* pol = (float*)tmp_alloc(sizeof(float) * (size_t)ctx->PD * ctx->PC);
     ora_polar(ctx, shifted, pol);
     ora_fft(ctx, pol, ctx->PD, ctx->PC, fft_polar);
-    free(pol); free(power); free(mag);
+    tmp_free(pol); tmp_free(power); tmp_free(mag);
 }
 
 /* Eigen-like reduction order: 16 interleaved float accumulators, then a pairwise fold
@@ -486,13 +509,13 @@ static void normalise_and_fft(ora_ctx* ctx, float* kernel, int rows, int cols, o
 /* polynomial_kernel  correlation_flow.cc:208-226 (xf == zf for the one-argument overload) */
 static void polynomial_kernel(ora_ctx* ctx, const ora_cf32* xf, const ora_cf32* zf, int rows, int cols, ora_cf32* out) {
     const int hr = rows / 2 + 1; const size_t nc = (size_t)hr * cols; const long n = (long)rows * cols;
-    ora_cf32* xzf = (ora_cf32*)malloc(sizeof(ora_cf32) * nc);
+    ora_cf32* xzf = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * nc);
     for (size_t i = 0; i < nc; ++i) xzf[i] = cmul(xf[i], cconj(zf[i]));
-    float* xz = (float*)malloc(sizeof(float) * (size_t)n);
+    float* xz = (float*)tmp_alloc(sizeof(float) * (size_t)n);
     ora_ifft(ctx, xzf, hr, cols, xz);
     for (long i = 0; i < n; ++i) xz[i] = pow_int(xz[i] + ctx->cfg.offset, ctx->cfg.power);
     normalise_and_fft(ctx, xz, rows, cols, out);
-    free(xz); free(xzf);
+    tmp_free(xz); tmp_free(xzf);
 }
 
 /* gaussian_kernel  correlation_flow.cc:181-206.  NOTE: xf.square().abs().sum() runs over the
@@ -500,15 +523,15 @@ static void polynomial_kernel(ora_ctx* ctx, const ora_cf32* xf, const ora_cf32* 
 static void gaussian_kernel(ora_ctx* ctx, const ora_cf32* xf, const ora_cf32* zf, int rows, int cols, ora_cf32* out) {
     const int hr = rows / 2 + 1; const size_t nc = (size_t)hr * cols; const long n = (long)rows * cols;
     const unsigned int N = (unsigned int)(rows * cols);
-    float* tmp = (float*)malloc(sizeof(float) * nc);
+    float* tmp = (float*)tmp_alloc(sizeof(float) * nc);
     for (size_t i = 0; i < nc; ++i) { ora_cf32 s = cmul(xf[i], xf[i]); tmp[i] = hypotf(s.re, s.im); }
     const float xx = sum16(tmp, (long)nc) / (float)N;
     for (size_t i = 0; i < nc; ++i) { ora_cf32 s = cmul(zf[i], zf[i]); tmp[i] = hypotf(s.re, s.im); }
     const float zz = sum16(tmp, (long)nc) / (float)N;
-    free(tmp);
-    ora_cf32* xzf = (ora_cf32*)malloc(sizeof(ora_cf32) * nc);
+    tmp_free(tmp);
+    ora_cf32* xzf = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * nc);
     for (size_t i = 0; i < nc; ++i) xzf[i] = cmul(xf[i], cconj(zf[i]));
-    float* xz = (float*)malloc(sizeof(float) * (size_t)n);
+    float* xz = (float*)tmp_alloc(sizeof(float) * (size_t)n);
     ora_ifft(ctx, xzf, hr, cols, xz);
     const float coef = -1 / (ctx->cfg.sigma * ctx->cfg.sigma);
     for (long i = 0; i < n; ++i) {
@@ -516,7 +539,7 @@ static void gaussian_kernel(ora_ctx* ctx, const ora_cf32* xf, const ora_cf32* zf
         xz[i] = expf(coef * xxzz);
     }
     normalise_and_fft(ctx, xz, rows, cols, out);
-    free(xz); free(xzf);
+    tmp_free(xz); tmp_free(xzf);
 }
 
 /* EstimateTrans  correlation_flow.cc:145-179 */
@@ -527,7 +550,7 @@ float ora_estimate_trans(ora_ctx* ctx, const ora_cf32* last_fft, const ora_cf32*
     const int hr = height / 2 + 1; const size_t nc = (size_t)hr * width; const long n = (long)height * width;
     if (err) *err = 0;
     if (ctx->cfg.kernel != 0 && ctx->cfg.kernel != 1) { if (err) *err = -1; return NAN; }   /* :167-168 throw */
-    ora_cf32* Kzz = (ora_cf32*)malloc(sizeof(ora_cf32) * nc * 2);
+    ora_cf32* Kzz = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * nc * 2);
     ora_cf32* Kxz = Kzz + nc;
     if (ctx->cfg.kernel == 0) {
         polynomial_kernel(ctx, last_fft, last_fft, height, width, Kzz);
@@ -543,7 +566,7 @@ float ora_estimate_trans(ora_ctx* ctx, const ora_cf32* last_fft, const ora_cf32*
         const ora_cf32 Hh = { (num.re * den.re + num.im * den.im) / d, (num.im * den.re - num.re * den.im) / d };
         Kzz[i] = cmul(Hh, Kxz[i]);
     }
-    float* g = g_out ? g_out : (float*)malloc(sizeof(float) * (size_t)n);
+    float* g = g_out ? g_out : (float*)tmp_alloc(sizeof(float) * (size_t)n);
     ora_ifft(ctx, Kzz, hr, width, g);
     /* :175 g.maxCoeff(&row,&col): Eigen visitor, column-major traversal, first strict max [recalled] */
     long best = 0; float response = g[0];
@@ -568,8 +591,8 @@ float ora_estimate_trans(ora_ctx* ctx, const ora_cf32* last_fft, const ora_cf32*
     if (prow) *prow = row;
     if (pcol) *pcol = col;
     const float info = ora_get_info(g, n, response);
-    if (!g_out) free(g);
-    free(Kzz);
+    if (!g_out) tmp_free(g);
+    tmp_free(Kzz);
     return info;
 }
 
@@ -581,9 +604,9 @@ int ora_compute_pose(ora_ctx* ctx, const ora_cf32* last_fft_result, const float*
     double trans[2] = { 0, 0 }, trans_orig[2], trans_veri[2], rots[2];
     int err = 0, rr = 0, rc = 0;
     ora_pose_debug d; memset(&d, 0, sizeof(d));
-    float* grot = (float*)malloc(sizeof(float) * (size_t)ctx->PD * ctx->PC);
+    float* grot = (float*)tmp_alloc(sizeof(float) * (size_t)ctx->PD * ctx->PC);
     const float info_rots = ora_estimate_trans(ctx, last_fft_polar, fft_polar, 1, rots, &rr, &rc, grot, &err);   /* :103 */
-    if (err) { free(grot); return -1; }
+    if (err) { tmp_free(grot); return -1; }
     float info_rots_used = info_rots;
     if (ctx->force_rot_row >= 0) {          /* test hook: another (near-tied) position of the same surface */
         rr = ctx->force_rot_row; rc = ctx->force_rot_col;
@@ -594,12 +617,12 @@ int ora_compute_pose(ora_ctx* ctx, const ora_cf32* last_fft_result, const float*
     d.rot_row = rr; d.rot_col = rc; d.psr_rot = info_rots_used;
     d.rot_peak = grot[(size_t)rc * ctx->PD + rr];
     d.rot_mirror = grot[(size_t)rc * ctx->PD + (rr + ctx->PD / 2) % ctx->PD];
-    free(grot);
+    tmp_free(grot);
     float degree = (float)(rots[0] * (2.0 / ctx->cfg.rotation_divisor) * 180);      /* :105 */
     degree = (float)ora_normalize_degree(degree);                                      /* :106 */
     float info_trans;
-    float* rot = (float*)malloc(sizeof(float) * n);
-    ora_cf32* frot = (ora_cf32*)malloc(sizeof(ora_cf32) * nc);
+    float* rot = (float*)tmp_alloc(sizeof(float) * n);
+    ora_cf32* frot = (ora_cf32*)tmp_alloc(sizeof(ora_cf32) * nc);
     if (not_large_rotation) {
         degree = fabsf(degree) > 90 ? degree - 180 : degree;                           /* :108 */
         ora_rotate(image, H, W, -degree, rot);                                          /* :109 */
@@ -626,13 +649,13 @@ int ora_compute_pose(ora_ctx* ctx, const ora_cf32* last_fft_result, const float*
     d.degree_final = degree;
     /* :139-140 std::cout omitted (I/O) */
     if (faithful) {                                                                     /* :141 dead `rectify` */
-        float* back = (float*)malloc(sizeof(float) * n * 2);
+        float* back = (float*)tmp_alloc(sizeof(float) * n * 2);
         ora_ifft(ctx, last_fft_result, H / 2 + 1, W, back);
         ora_warp(back, H, W, (float)-pose[0], (float)-pose[1], degree, back + n);
-        free(back);
+        tmp_free(back);
     }
     if (dbg) *dbg = d;
-    free(rot); free(frot);
+    tmp_free(rot); tmp_free(frot);
     return 0;
 }
 
@@ -653,6 +676,7 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
     #pragma omp parallel reduction(+:t_key)
     {
         ora_ctx* ctx = ora_create(cfg, H, W);                  /* per-thread context: set-up is not part of the timed units */
+        if (ctx) tmp_reserve((size_t)48 * sizeof(ora_cf32) * ((size_t)(H / 2 + 1) * W + (size_t)(ctx->PD / 2 + 1) * ctx->PC));
         const size_t npx = (size_t)H * W, nc = (size_t)(H / 2 + 1) * W;
         const size_t ncp = ctx ? (size_t)(ctx->PD / 2 + 1) * ctx->PC : 0;
         float* img = (float*)malloc(sizeof(float) * npx);
@@ -677,7 +701,7 @@ int ora_track_pairs(const ora_config* cfg, int H, int W, int n, const uint8_t* k
         }
         #pragma omp master
         t_total = now_s() - t_wall0;
-        free(img); free(kf); ora_destroy(ctx);
+        free(img); free(kf); ora_destroy(ctx); tmp_release();
     }
     /* wall time of the timed units = total wall minus the (thread-averaged) key preparation */
     if (seconds_unit) *seconds_unit = t_total - t_key / nthreads;

@@ -104,6 +104,7 @@ int nik_upload_u8_async(nik_ctx*, int n, const uint8_t* gray, int stride, size_t
 }
 int nik_upload_fence(nik_ctx*, int) { return NIK_OK; }
 int nik_upload_wait(nik_ctx*) { return NIK_OK; }
+int nik_upload_after_compute(nik_ctx*) { return NIK_OK; }
 int nik_map_add_frame(nik_map*, int32_t, nik_frame, const double*, const double*) { return NIK_OK; }
 int nik_map_find_loop(nik_map*, int32_t, const double*, nik_loop_result* out) { memset(out, 0, sizeof(*out)); return NIK_OK; }
 int nik_map_update_poses(nik_map*, int, const int32_t*, const double*) { return NIK_OK; }

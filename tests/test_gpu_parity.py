@@ -4,6 +4,7 @@ Tolerances: arg-max indices bit-exact (see kcc_helpers.check_pose_parity for the
 rotation tie); gathers bit-exact; FFT-derived float planes within 2e-5 of the plane's max |value|
 (float32 FFT rounding); PSR within 2e-3 relative.
 """
+import os
 import numpy as np
 import pytest
 
