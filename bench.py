@@ -151,6 +151,49 @@ def _line(metric, unit, value, world, args, ms_per_step, workload, bytes_per_uni
     return out
 
 
+def _make_group(N, torch, dist, np, cf, rank, world, dev, what):
+    """the library's nik_group for this rank (RCCL inside the C ABI).  Returns (group or None, description, fallback, stats_t):
+    with the test hook NIK_BENCH_BACKEND=gloo (several ranks on one device, where RCCL cannot form a communicator) or when the
+    group cannot be created, the exchange runs through torch.distributed instead and the line says so."""
+    comm, grp, stats_t, fallback = "nik_group (single GPU: no collective)", None, None, False
+    if world > 1 and os.environ.get("NIK_BENCH_BACKEND", "nccl") != "nccl":
+        cf.set_residual_stats(True)
+        stats_t = torch.zeros(4, dtype=torch.float64)
+        comm = "device-side reduction + torch.distributed(%s) %s [test hook]" % (os.environ["NIK_BENCH_BACKEND"], what)
+        return grp, comm, fallback, stats_t
+    try:
+        uid = None
+        if world > 1:
+            t = torch.from_numpy(N.Group.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
+            dist.broadcast(t, src=0)
+            uid = t.cpu().numpy()
+            comm = "nik_group: RCCL %s inside the C ABI" % what
+        grp = N.Group.rank(cf, rank, world, uid)
+    except Exception as e:                                   # keep the measurement alive; say so in the line
+        grp, fallback = None, True
+        cf.set_residual_stats(True)
+        stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
+        comm = "FALLBACK torch.distributed %s (nik_group failed: %s)" % (what, str(e)[:200])
+    if world > 1:
+        # every rank must take the same road: a communicator that formed on some ranks only would leave them waiting in RCCL
+        # for the ranks that fell back to torch.distributed
+        ok = torch.tensor([0 if fallback else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and grp is not None:
+            grp.close()
+            grp, fallback = None, True
+            cf.set_residual_stats(True)
+            stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
+            comm = "FALLBACK torch.distributed %s (nik_group failed on another rank)" % what
+    return grp, comm, fallback, stats_t
+
+
+def _multi_gpu_facts(N, world, grp, fallback, **more):
+    lib, shared = N.Group.rccl_library() if (grp is not None and world > 1) or os.environ.get("NIK_GROUP_FORCE_RCCL") else (None, False)
+    return dict(dict(world=world, rccl_ranks=grp.comm_ranks() if grp is not None else 0, fallback=bool(fallback),
+                     rccl_library=lib, rccl_shared_with_torch=bool(shared)), **more)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank, hd=False):
     """The headline workload (hd=False: 640x480 gray pairs) and configs[3] (hd=True: 1280x720 RGB frames -> integer luma ->
@@ -196,36 +239,7 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
 
     # the residual all-reduce: through the library's nik_group (RCCL inside the C ABI).  Test hook NIK_BENCH_BACKEND=gloo
     # (several ranks on one device, where RCCL cannot form a communicator): device-side reduction + torch.distributed.
-    comm, grp, stats_t, fallback = "nik_group (single GPU: no collective)", None, None, False
-    if world > 1 and os.environ.get("NIK_BENCH_BACKEND", "nccl") != "nccl":
-        cf.set_residual_stats(True)
-        stats_t = torch.zeros(4, dtype=torch.float64)
-        comm = "device-side reduction + torch.distributed(%s) all-reduce [test hook]" % os.environ["NIK_BENCH_BACKEND"]
-    else:
-        try:
-            uid = None
-            if world > 1:
-                t = torch.from_numpy(N.Group.unique_id() if rank == 0 else np.zeros(128, np.uint8)).to(dev)
-                dist.broadcast(t, src=0)
-                uid = t.cpu().numpy()
-                comm = "nik_group: RCCL all-reduce of 4 doubles per step inside the C ABI"
-            grp = N.Group.rank(cf, rank, world, uid)
-        except Exception as e:                                   # keep the measurement alive; say so in the line
-            grp, fallback = None, True
-            cf.set_residual_stats(True)
-            stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
-            comm = "FALLBACK torch.distributed all-reduce (nik_group failed: %s)" % str(e)[:200]
-        if world > 1:
-            # every rank must take the same road: a communicator that formed on some ranks only would leave them waiting in RCCL
-            # for the ranks that fell back to torch.distributed
-            ok = torch.tensor([0 if fallback else 1], dtype=torch.int32, device=dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0 and grp is not None:
-                grp.close()
-                grp, fallback = None, True
-                cf.set_residual_stats(True)
-                stats_t = torch.zeros(4, dtype=torch.float64, device=dev)
-                comm = "FALLBACK torch.distributed all-reduce (nik_group failed on another rank)"
+    grp, comm, fallback, stats_t = _make_group(N, torch, dist, np, cf, rank, world, dev, "all-reduce of 4 doubles per step")
 
     # The library keeps two calls in flight per stream; results of step k are final once step k+2 has been queued (or after
     # synchronize()).  Nothing in the loop touches per-pair results on the host.
@@ -357,9 +371,9 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
                     bpp, dict(pairs_per_gpu_per_step=B, unique_pairs=U, parallelism="pairs sharded x%d" % world, residual_allreduce=comm),
                     roofline=_roofline(kernels, B, live), cpu_baseline=cpu, parity_spot_check=parity_ok,
                     residual_stats=None if stats is None else [float(v) for v in stats], timing=timing,
-                    multi_gpu=dict(world=world, rccl_ranks=rccl_ranks, fallback=bool(fallback),
+                    multi_gpu=_multi_gpu_facts(N, world, grp, fallback,
                                    pairs_per_s_per_rank_min=round(min(rank_rates), 1), pairs_per_s_per_rank_max=round(max(rank_rates), 1),
-                                   note="rccl_ranks = ncclCommCount of the library's communicator (0: one GPU, no collective); fallback: the residual all-reduce ran through torch.distributed instead of nik_group"),
+                                   note="rccl_ranks = ncclCommCount of the library's communicator (0: one GPU, no collective); fallback: the residual all-reduce ran through torch.distributed instead of nik_group; rccl_library: the file the library's ncclAllReduce came from, rccl_shared_with_torch: it is the copy PyTorch had loaded (RTLD_NOLOAD)"),
                     kzz_cached_mode=None if pairs_per_s_cached is None else {
                         "value_per_gpu": round(pairs_per_s_cached, 1), "bytes_per_pair": bpc,
                         "frac_of_8TBps": round(pairs_per_s_cached * bpc / HBM_PEAK, 4),
@@ -525,54 +539,125 @@ def workload_pyramid(args, N, torch, np, synth, dev, local_rank):
     return out
 
 
-def workload_loop(args, N, torch, np, synth, dev, local_rank):
+def workload_loop(args, N, torch, dist, np, synth, world, rank, dev, local_rank):
+    """configs[4]; with --gpus N the CANDIDATE SET is sharded (contiguous shards of the key-frame store, the query
+    handed to every rank, every rank's best record all-gathered, winner by src/loop_closure.cc:61-65 with ties to the lowest
+    global index) -- strong scaling: the 4096 candidates are the job whatever N is."""
     H, W, PD, PC = 480, 640, 720, 480
     NC, MB = args.candidates, 128
-    cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=MB, max_frames=NC + 1, device=local_rank)
+    b0, e0 = N.Group.shard(NC, world, rank)
+    nloc = e0 - b0
+    cf = N.CorrelationFlow(N.default_config(), H, W, max_batch=MB, max_frames=nloc + 1, device=local_rank)
     cv = [synth.canvas(900 + i, H, W) for i in range(8)]
     U = 64
     uniq = np.stack([synth.window(cv[i % 8], H, W, (7 * i) % 120 - 60, (5 * i) % 160 - 80, 0.5 * (i % 11)) for i in range(U)])
-    d = torch.from_numpy(np.tile(uniq, (MB // U, 1, 1))).to(dev); torch.cuda.synchronize()
-    for b in range(0, NC, MB):
-        m = min(MB, NC - b)
-        cf.intermedium_batch_dev(d.data_ptr(), m, list(range(b, b + m)))
+    d_uniq = torch.from_numpy(uniq).to(dev)
+    for b in range(b0, e0, MB):                                     # candidate i of the global store shows place i % U
+        m = min(MB, e0 - b)
+        d = d_uniq[torch.arange(b, b + m, device=dev) % U].contiguous()
+        cf.intermedium_batch_dev(d.data_ptr(), m, list(range(b - b0, b - b0 + m)))
+        cf.synchronize()
     true_idx = 44                                                   # (rotation 0: 44 % 11 == 0) candidates i with i % 64 == 44 hold the query's place
     q = synth.window(cv[true_idx % 8], H, W, (7 * true_idx) % 120 - 60 + 3, (5 * true_idx) % 160 - 80 - 4, 0.0)
-    cf.intermedium_u8(q, NC)
+    cf.intermedium_u8(q, nloc)                                      # "broadcast the query": every rank computes its spectra
     cf.synchronize()
-    cands = list(range(NC))
+    cands = list(range(nloc))
+    grp, comm, fallback, _ = (None, "nik_group (single GPU: no collective)", False, None) if world == 1 else \
+        _make_group(N, torch, dist, np, cf, rank, world, dev, "all-gather of every rank's best record (8 doubles) per query")
+    cdev = dev if (world > 1 and dist.get_backend() == "nccl") else "cpu"
+
+    def gather(best, br):
+        """this rank's best (local index, result) -> the group's winner (global index, result dict)"""
+        if world == 1:
+            return best, br
+        gi = b0 + best if best >= 0 else -1
+        if grp is not None:
+            return grp.gather_best([gi], [br])
+        rec = torch.zeros(8, dtype=torch.float64)
+        if gi >= 0:
+            rec[0] = br.info[0] + br.info[1] + br.info[2]; rec[1] = gi
+            for k in range(3):
+                rec[2 + k] = br.pose[k]; rec[5 + k] = br.info[k]
+        else:
+            rec[1] = -1
+        allr = [torch.zeros(8, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(allr, rec.to(cdev))
+        R = np.stack([x.cpu().numpy() for x in allr])
+        w = N.Group.pick_best(R)
+        return (int(R[w, 1]), dict(pose=R[w, 2:5].tolist(), info=R[w, 5:8].tolist())) if w >= 0 else (-1, None)
+
+    def query(fn):
+        best, _, br = fn()
+        return gather(best, br)
 
     def timed(fn, reps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
-        return (time.perf_counter() - t0) / reps
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt_own = (time.perf_counter() - t0) / reps
+        if world == 1:
+            return dt_own, [dt_own]
+        t = torch.tensor([dt_own], dtype=torch.float64, device=cdev)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        own = [float(x.item()) for x in allt]
+        return max(own), own
     reps = max(1, args.steps // 5)
+    exact = lambda: query(lambda: cf.match(nloc, cands, raw=True))
     for _ in range(max(1, args.warmup // 2)):
+        exact()
+    dt, dt_ranks = timed(exact, reps)                                        # exact search, the reference's work per candidate
+    dt2 = dt3 = None
+    if world == 1:
+        dt2, _ = timed(lambda: cf.match_topk(NC, cands, 16), reps)
+        cf.set_kzz_cache(True)                                               # key frames are resident: their Kzz can be too
         cf.match(NC, cands, raw=True)
-    dt = timed(lambda: cf.match(NC, cands, raw=True), reps)                 # exact search, the reference's work per candidate
-    dt2 = timed(lambda: cf.match_topk(NC, cands, 16), reps)
-    cf.set_kzz_cache(True)                                                   # key frames are resident: their Kzz can be too
-    cf.match(NC, cands, raw=True)
-    dt3 = timed(lambda: cf.match(NC, cands, raw=True), reps)
-    cf.set_kzz_cache(False)
-    best, res, br = cf.match(NC, cands)
-    b2, r2, short = cf.match_topk(NC, cands, 16)
+        dt3, _ = timed(lambda: cf.match(NC, cands, raw=True), reps)
+        cf.set_kzz_cache(False)
+    best, rr, br_raw = cf.match(nloc, cands, raw=True)
+    res, br = [rr[i].as_dict() for i in range(nloc)], br_raw.as_dict()
+    gbest, gres = gather(best, br_raw)
+    if world == 1:
+        gres = br
     # size-independent properties at the full size: the winner is the first copy of the true place; every copy of a place scores
-    # the same; the short-list search finds the same score
+    # the same (on every rank); the short-list search finds the same score
     scores = np.array([sum(r["info"]) for r in res])
-    prop = bool(best == true_idx and (br["pose"][0], br["pose"][1]) == (-4, 3) and all(np.all(scores[k::U] == scores[k]) for k in range(U))
-                and abs(sum(r2["info"]) - sum(br["info"])) < 1e-9 and int(scores.argmax()) == best)
+    first = {k: next((i for i in range(nloc) if (b0 + i) % U == k), None) for k in range(U)}
+    same = all(np.all(scores[np.arange(first[k], nloc, U)] == scores[first[k]]) for k in range(U) if first[k] is not None)
+    prop = bool(gbest == true_idx and gres is not None and (gres["pose"][0], gres["pose"][1]) == (-4, 3) and same)
+    extra = {}
+    if world == 1:
+        b2, r2, short = cf.match_topk(NC, cands, 16)
+        prop = bool(prop and abs(sum(r2["info"]) - sum(br["info"])) < 1e-9 and int(scores.argmax()) == best)
+        extra = dict(
+            topk16={"candidates_per_s": round(NC / dt2, 1), "ms_per_query": round(1e3 * dt2, 3), "same_best_score": bool(abs(sum(r2["info"]) - sum(br["info"])) < 1e-9),
+                    "note": "extension: rank by rotation-stage PSR, full ComputePose on the top 16"},
+            kzz_cached_mode={"candidates_per_s": round(NC / dt3, 1), "ms_per_query": round(1e3 * dt3, 3),
+                             "bytes_per_candidate": algorithmic_bytes(H, W, PD, PC, kzz_cached=True, hypotheses=2, with_intermedium=False),
+                             "frac_of_8TBps": round(NC / dt3 * algorithmic_bytes(H, W, PD, PC, kzz_cached=True, hypotheses=2, with_intermedium=False) / HBM_PEAK, 4),
+                             "note": "exact search with the per-keyframe Kzz cache (identical results; the key frames are resident anyway)"})
+    if os.environ.get("NIK_BENCH_DUMP"):                            # test hook: the group's winner as this rank sees it
+        json.dump(dict(rank=rank, world=world, best=gbest, result=gres, shard=[b0, e0]), open(os.environ["NIK_BENCH_DUMP"] + ".%d" % rank, "w"))
     bpc = algorithmic_bytes(H, W, PD, PC, hypotheses=2, with_intermedium=False)
-    out = _line("loop-closure candidates/s, exact two-hypothesis ComputePose over resident key frames (configs[4])", "candidates/s", NC / dt, 1, args, 1e3 * dt,
-                "configs[4]: 1 query x %d resident key frames (%.1f GB of spectra), not_large_rotation=false on every candidate, strict-> winner" % (NC, NC * 2.62e6 / 1e9),
-                bpc, dict(candidates=NC, chunk=MB), parity_spot_check=prop, roofline=None, cpu_baseline=None,
-                topk16={"candidates_per_s": round(NC / dt2, 1), "ms_per_query": round(1e3 * dt2, 3), "same_best_score": bool(abs(sum(r2["info"]) - sum(br["info"])) < 1e-9),
-                        "note": "extension: rank by rotation-stage PSR, full ComputePose on the top 16"},
-                kzz_cached_mode={"candidates_per_s": round(NC / dt3, 1), "ms_per_query": round(1e3 * dt3, 3),
-                                 "bytes_per_candidate": algorithmic_bytes(H, W, PD, PC, kzz_cached=True, hypotheses=2, with_intermedium=False),
-                                 "frac_of_8TBps": round(NC / dt3 * algorithmic_bytes(H, W, PD, PC, kzz_cached=True, hypotheses=2, with_intermedium=False) / HBM_PEAK, 4),
-                                 "note": "exact search with the per-keyframe Kzz cache (identical results; the key frames are resident anyway)"})
+    out = None
+    if rank == 0:
+        out = _line("loop-closure candidates/s, exact two-hypothesis ComputePose over resident key frames (configs[4])", "candidates/s", NC / dt, world, args, 1e3 * dt,
+                    "configs[4]: 1 query x %d resident key frames (%.1f GB of spectra), not_large_rotation=false on every candidate, strict-> winner" % (NC, NC * 2.62e6 / 1e9),
+                    bpc, dict(candidates=NC, chunk=MB, parallelism="candidate set sharded x%d (contiguous shards, lowest global index wins ties)" % world, best_exchange=comm),
+                    parity_spot_check=prop, roofline=None, cpu_baseline=None, winner=dict(index=gbest, result=gres),
+                    multi_gpu=_multi_gpu_facts(N, world, grp, fallback, candidates_per_rank=[N.Group.shard(NC, world, r)[1] - N.Group.shard(NC, world, r)[0] for r in range(world)],
+                                               ms_per_query_per_rank=[round(1e3 * x, 3) for x in dt_ranks],
+                                               note="strong scaling: the candidate set is the job; every query ends with one all-gather of 8 doubles per rank"),
+                    **extra)
+        out["scaling"] = "strong" if world > 1 else "weak"
+    if grp is not None:
+        grp.close()
     cf.close()
     return out
 
@@ -605,7 +690,7 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if env_world is None and args.gpus > 1:
-        if args.workload not in ("pairs", "hd"):
+        if args.workload not in ("pairs", "hd", "loop4096"):
             raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
         port = os.environ.get("MASTER_PORT") or str(29500 + os.getpid() % 2000)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
@@ -643,6 +728,8 @@ def main():
 
     if args.workload in ("pairs", "hd"):
         out = workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank, hd=args.workload == "hd")
+    elif args.workload == "loop4096":
+        out = workload_loop(args, N, torch, dist, np, synth, world, rank, dev, local_rank)
     elif world > 1:
         raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
     elif args.workload == "sequence":
@@ -650,7 +737,7 @@ def main():
     elif args.workload == "pyramid":
         out = workload_pyramid(args, N, torch, np, synth, dev, local_rank)
     else:
-        out = workload_loop(args, N, torch, np, synth, dev, local_rank)
+        raise SystemExit("unknown workload %s" % args.workload)
     if rank == 0 and out is not None:
         print(json.dumps(out))
     if world > 1:

@@ -495,6 +495,11 @@ void nik_group_shard(int n, int world, int rank, int* begin, int* end);
  * none), pose x3, info x3]: strictly larger score wins, equal scores go to the lowest rank = the first candidate in global
  * order.  Returns the winning rank, -1 if no rank has a candidate.  Host-only (what nik_group_gather_best applies). */
 int  nik_group_pick_best(const double* records, int world);
+/* the RCCL the library bound: path of the file ncclAllReduce came from (NULL: RCCL not loaded / not found) and whether it is the
+ * copy the host process had already loaded (*shared_with_host = 1, e.g. PyTorch's) or one the library loaded itself.
+ * nik_group_create_rank gives ncclCommInitRank $NIK_GROUP_INIT_TIMEOUT seconds (default 90; <= 0: no limit) and fails with a
+ * message instead of blocking for good. */
+const char* nik_group_rccl_library(int* shared_with_host);
 /* ranks the group's RCCL communicator spans (ncclCommCount); 0 = the group runs without RCCL (one member) */
 int  nik_group_comm_ranks(const nik_group* g);
 /* sum over the group of every member's latest-batch statistics (nik_set_residual_stats is switched on by the group),

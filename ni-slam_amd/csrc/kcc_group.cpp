@@ -32,9 +32,12 @@ typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3, ncclAvg = 4 
 #endif
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -55,6 +58,8 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
+    std::string path;           // file the symbols were bound from (dladdr of ncclAllReduce)
+    bool shared = false;        // the host process had already loaded it (RTLD_NOLOAD hit: e.g. PyTorch's RCCL)
     bool ok = false;
 };
 
@@ -68,6 +73,7 @@ Rccl& rccl() {
 static void rccl_load(Rccl& r) {
     for (const char* name : { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" }) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);          // reuse a copy the host process already loaded
+        r.shared = r.lib != nullptr;
         if (!r.lib) r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
     }
@@ -77,7 +83,38 @@ static void rccl_load(Rccl& r) {
     SYM(CommDestroy, "ncclCommDestroy"); SYM(CommCount, "ncclCommCount"); SYM(AllReduce, "ncclAllReduce"); SYM(AllGather, "ncclAllGather");
     SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    Dl_info info;
+    if (dladdr((void*)r.AllReduce, &info) && info.dli_fname) r.path = info.dli_fname;
     r.ok = true;
+}
+
+// ncclCommInitRank with a deadline.  The first communicator of a multi-GPU job forms here -- inside a process that may already
+// carry the launcher's own RCCL world -- and a rank that never arrives (or a bootstrap that cannot connect) makes the call
+// block for good: a benchmark driver would then see a timeout instead of a line.  The call runs on a helper thread; past
+// $NIK_GROUP_INIT_TIMEOUT seconds (default 90) the group creation FAILS with a clear message (the caller falls back or
+// reports), and the helper thread -- still inside RCCL -- is left detached with its own copy of everything it touches.
+struct InitJob { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; std::string hip_err; };
+static int comm_init_rank_deadline(int device, int world, const ncclUniqueId& u, int rank, ncclComm_t* out, std::string& err) {
+    const char* e = getenv("NIK_GROUP_INIT_TIMEOUT");
+    const double limit = e ? atof(e) : 90.0;
+    auto job = std::make_shared<InitJob>();
+    std::thread([job, device, world, u, rank] {
+        ncclComm_t c = nullptr; ncclResult_t r = ncclSuccess; std::string he;
+        const hipError_t h = hipSetDevice(device);
+        if (h != hipSuccess) he = std::string("hipSetDevice: ") + hipGetErrorString(h);
+        else r = rccl().CommInitRank(&c, world, u, rank);
+        std::lock_guard<std::mutex> lk(job->mu);
+        job->comm = c; job->res = r; job->hip_err = he; job->done = true;
+        job->cv.notify_all();
+    }).detach();
+    std::unique_lock<std::mutex> lk(job->mu);
+    const bool in_time = limit <= 0 ? (job->cv.wait(lk, [&] { return job->done; }), true)
+                                    : job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; });
+    if (!in_time) { err = "ncclCommInitRank did not return within " + std::to_string((int)limit) + " s (rank " + std::to_string(rank) + " of " + std::to_string(world) + "; $NIK_GROUP_INIT_TIMEOUT)"; return NIK_ERR_HIP; }
+    if (!job->hip_err.empty()) { err = job->hip_err; return NIK_ERR_HIP; }
+    if (job->res != ncclSuccess) { err = std::string("ncclCommInitRank: ") + rccl().GetErrorString(job->res); return NIK_ERR_HIP; }
+    *out = job->comm;
+    return NIK_OK;
 }
 
 thread_local std::string g_group_error;
@@ -168,6 +205,14 @@ int nik_group_comm_ranks(const nik_group* g) {
     return rccl().CommCount(g->m[0].comm, &n) == ncclSuccess ? n : -1;
 }
 
+// which RCCL the library bound (machine-checkable fact for bench.py's multi_gpu object): the file of ncclAllReduce, and whether
+// it was the copy the host process had already loaded (PyTorch's) or one this library loaded itself.  NULL: RCCL not loaded.
+const char* nik_group_rccl_library(int* shared_with_host) {
+    Rccl& r = rccl();
+    if (shared_with_host) *shared_with_host = r.shared ? 1 : 0;
+    return r.ok ? r.path.c_str() : nullptr;
+}
+
 int nik_group_unique_id(uint8_t id[NIK_GROUP_ID_BYTES]) {
     if (!id) return NIK_ERR_INVALID_ARG;
     static_assert(sizeof(ncclUniqueId) <= NIK_GROUP_ID_BYTES, "unique id does not fit");
@@ -212,8 +257,8 @@ int nik_group_create_rank(nik_ctx* ctx, int rank, int world, const uint8_t id[NI
             ncclUniqueId u;
             if (id) memcpy(&u, id, sizeof(u));
             else if (rccl().GetUniqueId(&u) != ncclSuccess) memset(&u, 0, sizeof(u));
-            ncclResult_t r = rccl().CommInitRank(&mb.comm, world, u, rank);
-            if (r != ncclSuccess) rc = gfail(g, NIK_ERR_HIP, std::string("ncclCommInitRank: ") + rccl().GetErrorString(r));
+            std::string ierr;
+            if (comm_init_rank_deadline(mb.device, world, u, rank, &mb.comm, ierr)) rc = gfail(g, NIK_ERR_HIP, ierr);
         }
     }
     if (rc) { g_group_error = g->err; nik_group_destroy(g); return rc; }

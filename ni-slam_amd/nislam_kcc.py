@@ -25,7 +25,7 @@ EXPORTS = ["nik_create", "nik_destroy", "nik_last_error", "nik_get_dims", "nik_s
            "nik_frame_import", "nik_pose", "nik_pose_batch", "nik_track_batch_dev", "nik_match",
            "nik_dbg_fft", "nik_dbg_ifft", "nik_dbg_rotate", "nik_dbg_polar", "nik_dbg_response",
            "nik_profile_enable", "nik_profile_read", "nik_set_streams", "nik_set_chunk",
-           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_is_generic", "nik_host_fft_plan", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_push_host", "nik_tracker_prefetch_dev", "nik_upload_u8_async", "nik_upload_fence", "nik_upload_wait", "nik_upload_after_compute", "nik_dev_malloc", "nik_dev_free", "nik_tracker_keyframes",
+           "nik_match_topk", "nik_rgb_to_gray_dev", "nik_set_kzz_cache", "nik_camera_maps", "nik_set_undistort", "nik_undistort_dev", "nik_tracker_create", "nik_tracker_destroy", "nik_is_generic", "nik_host_fft_plan", "nik_tracker_push_dev", "nik_tracker_push_u8", "nik_tracker_push_host", "nik_tracker_prefetch_dev", "nik_upload_u8_async", "nik_upload_fence", "nik_upload_wait", "nik_upload_after_compute", "nik_group_rccl_library", "nik_dev_malloc", "nik_dev_free", "nik_tracker_keyframes",
            "nik_tracker_attach_map", "nik_tracker_loops", "nik_pose_graph_optimize", "nik_pose_graph_optimize_dev", "nik_pose_graph_linearize", "nik_pg_shard_create", "nik_pg_shard_destroy", "nik_pg_shard_device", "nik_pg_shard_cost_dev", "nik_group_pose_graph_cost", "nik_stitcher_create", "nik_stitcher_destroy", "nik_stitcher_insert_dev", "nik_stitcher_recompute",
            "nik_stitcher_cells", "nik_stitcher_read_cell", "nik_pose_batch_window", "nik_downsample_u8_dev", "nik_pyramid_create", "nik_pyramid_destroy",
            "nik_pyramid_levels", "nik_pyramid_track_dev", "nik_pyramid_track_dev_async", "nik_pyramid_synchronize", "nik_pyramid_last_error",
@@ -247,6 +247,8 @@ def load():
         L.nik_group_shard.restype = None
         L.nik_group_pick_best.argtypes = [P, I]
         L.nik_group_comm_ranks.argtypes = [P]
+        L.nik_group_rccl_library.restype = C.c_char_p
+        L.nik_group_rccl_library.argtypes = [C.POINTER(C.c_int)]
         L.nik_group_allreduce_residual.argtypes = [P, P]
         L.nik_group_residual_result.argtypes = [P, P]
         L.nik_group_gather_best.argtypes = [P, P, P, P, P]
@@ -642,6 +644,13 @@ class Group:
         """records: [world][8] doubles (score, global index, pose x3, info x3) -> winning rank by the reference's rule (-1: none)"""
         r = np.ascontiguousarray(records, np.float64).reshape(-1, 8)
         return load().nik_group_pick_best(_p(r), int(r.shape[0]))
+
+    @staticmethod
+    def rccl_library():
+        """(path of the RCCL the library bound or None, True if it is the copy the host process -- PyTorch -- had already loaded)"""
+        sh = C.c_int(0)
+        p = load().nik_group_rccl_library(C.byref(sh))
+        return (p.decode() if p else None), bool(sh.value)
 
     def comm_ranks(self):
         """ranks the RCCL communicator spans (ncclCommCount); 0 = no RCCL in use"""

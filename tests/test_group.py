@@ -75,10 +75,33 @@ def test_local_group_of_one_gpu_equals_direct_calls():
 def test_group_through_rccl_single_rank():
     """the same checks with the collectives going through RCCL (own process: the switch is read at group creation)"""
     env = dict(os.environ, NIK_GROUP_FORCE_RCCL="1")
-    code = "import sys; sys.path[:0] = [%r, %r]; import test_group; test_group._group_checks(); print('RCCL-OK')" % (
+    code = ("import sys; sys.path[:0] = [%r, %r]; import test_group; test_group._group_checks(); "
+            "from kcc_helpers import nik; print('RCCL-LIB', *nik().Group.rccl_library()); print('RCCL-OK')") % (
         os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "RCCL-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
+    # which RCCL the library bound is a reported fact (bench.py's multi_gpu object): a path naming librccl, loaded by the library
+    # itself here (no torch in this process)
+    lib = [l for l in p.stdout.splitlines() if l.startswith("RCCL-LIB")][0].split()
+    assert "rccl" in lib[1] and lib[2] == "False", lib
+
+
+@pytest.mark.gpu
+def test_comm_init_deadline_turns_a_hang_into_an_error():
+    """a rank whose peers never arrive: nik_group_create_rank(world = 2) on its own returns an error after
+    $NIK_GROUP_INIT_TIMEOUT seconds instead of blocking in ncclCommInitRank for good (on the 8-GPU box a hang becomes a
+    `fallback: true` line, not a driver timeout).  A 2-rank RCCL communicator cannot FORM on one device -- that leg of
+    configs[3] stays for the 8-GPU node; what is tested here is the failure path."""
+    env = dict(os.environ, NIK_GROUP_INIT_TIMEOUT="4")
+    code = ("import sys, time; sys.path[:0] = [%r, %r]; from kcc_helpers import SMALL, nik; N = nik()\n"
+            "cf = N.CorrelationFlow(N.default_config(rotation_divisor=SMALL['PD'], rotation_channel=SMALL['PC']), SMALL['H'], SMALL['W'], max_batch=4, max_frames=4)\n"
+            "t0 = time.time()\n"
+            "try:\n    N.Group.rank(cf, 0, 2, N.Group.unique_id()); print('FORMED')\n"
+            "except Exception as e:\n    print('DEADLINE %%.1f' %% (time.time() - t0), str(e)[:200])\n"
+            "sys.stdout.flush(); import os; os._exit(0)\n") % (
+        os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "DEADLINE" in p.stdout and "did not return within 4 s" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
 def _run_bench(world, gb, dump, tmp_path, workload="pairs", bare=False):
@@ -138,6 +161,37 @@ def test_configs3_hd_two_ranks_equal_one_rank(tmp_path):
     assert mg["world"] == 2 and mg["fallback"] is False and mg["rccl_ranks"] == 0        # (gloo test hook: no RCCL communicator)
     assert 0 < mg["pairs_per_s_per_rank_min"] <= mg["pairs_per_s_per_rank_max"]
     assert line1["multi_gpu"]["world"] == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1800)
+def test_loop_closure_candidate_shards_two_ranks_equal_one_rank(tmp_path):
+    """SURVEY 8(e) loop closure: the CANDIDATE SET sharded over the ranks (contiguous shards, the query on every rank, every
+    rank's best record gathered, winner by loop_closure.cc:61-65 with ties to the lowest global index) -- `bench.py --workload
+    loop4096 --gpus 2` on one device (gloo rendezvous; a 2-rank RCCL communicator cannot form on one GPU) names the same winner
+    with the same score as the unsharded run, and three ranks (uneven shards) do too."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import json
+
+    def run(world):
+        dump = tmp_path / ("lc%d" % world)
+        env = dict(os.environ, NIK_BENCH_DUMP=str(dump), NIK_BENCH_DEVICE="0", NIK_BENCH_BACKEND="gloo")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+            env.pop(k, None)
+        p = subprocess.run([sys.executable, "bench.py", "--gpus", str(world), "--workload", "loop4096", "--candidates", "200", "--steps", "5", "--warmup", "2"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        return line, [json.load(open("%s.%d" % (dump, r))) for r in range(world)]
+    l1, d1 = run(1)
+    assert l1["parity_spot_check"] is True and l1["winner"]["index"] == 44 and l1["n_gpus"] == 1
+    for world in (2, 3):
+        lw, dw = run(world)
+        assert lw["n_gpus"] == world and lw["scaling"] == "strong" and lw["parity_spot_check"] is True
+        assert sum(lw["multi_gpu"]["candidates_per_rank"]) == 200 and lw["multi_gpu"]["world"] == world
+        for r in range(world):                                   # every rank sees the same winner: the unsharded run's
+            assert dw[r]["best"] == d1[0]["best"] == 44
+            assert dw[r]["result"]["pose"] == d1[0]["result"]["pose"][:3] and dw[r]["result"]["info"] == d1[0]["result"]["info"][:3]
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
