@@ -347,10 +347,12 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
             ocfg = ko.default_config()
             ncores = os.cpu_count() or 1
             ns = min(args.cpu_sample, U, 16 if hd else U)
-            # the oracle allocates plane-sized temporaries per call (like the reference's Eigen temporaries); on the 2x64-core
-            # host its throughput peaks at 16 threads and FALLS beyond (tools/cpu_scale.py, profiles/r04_cpu_scale.txt: 12 / 96 /
-            # 195 / 180 / 166 / 138 / 88 pairs/s at 1 / 8 / 16 / 32 / 64 / 128 / 256 threads), so the peak is what is reported
-            nthr = min(ncores, ns, 16)
+            # on the 2x64-core host the oracle's throughput peaks at 16-32 threads and FALLS beyond (tools/cpu_scale.py: 11 / 94 /
+            # 165 / 197 / 159 / 137 / 92 pairs/s at 1 / 8 / 16 / 32 / 64 / 128 / 256 threads, profiles/r05_cpu_scale.txt).  Round 5
+            # gave every thread one arena for its plane-sized temporaries (no malloc / mmap / page faults in the timed units): the
+            # curve did not move (r04: 12 / 96 / 195 / 180 / 166 / 138 / 88), so it is the memory system -- 10-30 MB of strided planes
+            # per thread against 32 MB of L3 per 8 cores -- not the allocator.  The peak is what is reported.
+            nthr = min(ncores, ns, 32)
             poses, infos, dbgs, secs_all = ko.track_pairs(ocfg, keys_u8[:ns], curs_u8[:ns], True, faithful=False, nthreads=nthr)
             parity_ok = all(check_pose_parity(last[i], poses[i], infos[i], dbgs[i], PD,
                                               rerun=imposed_rerun(ocfg, H, W, keys_u8[i], curs_u8[i], True))[0] for i in range(ns))

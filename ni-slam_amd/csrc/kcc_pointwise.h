@@ -43,11 +43,19 @@ __device__ __forceinline__ int affine_base(double m1, int r, double m2) {
 
 // (xz + offset)^power as Eigen's Array::pow(int) does it: double pow, rounded to float.  The general-power
 // path is kept out of line (it is ~100 instructions of libm pow per element).
-static __device__ __noinline__ float pow_generic(float b, int p) { return (float)pow((double)b, (double)p); }
+// oracle/RECALLED.md row 16 is an OPEN question: Eigen 3.3 may promote the integer exponent to the array's scalar first
+// (promote_scalar_arg), i.e. evaluate powf(x, 3.0f) -- one ulp away from the double evaluation on 6.6e-4 of the samples with
+// glibc (tests/test_toolchain_pins.py), never enough to move an index.  -DKCC_POLY_POWF=1 builds that reading (with the device
+// library's powf, itself within an ulp of glibc's); the oracle has the same switch (ora_set_pow_mode).
+#ifndef KCC_POLY_POWF
+#define KCC_POLY_POWF 0
+#endif
+static __device__ __noinline__ float pow_generic(float b, int p) { return KCC_POLY_POWF ? powf(b, (float)p) : (float)pow((double)b, (double)p); }
 enum { KT_POLY3 = 0, KT_POLYN = 1, KT_GAUSS = 2 };
 template <int KT>
 __device__ __forceinline__ float kernel_value(const KernelFn& fn, float xz, float gauss_bias, float gauss_scale) {
     if (KT == KT_POLY3) {
+        if (KCC_POLY_POWF) return powf(xz + fn.offset, 3.0f);
         const double b = (double)(xz + fn.offset);
         return (float)(b * b * b);
     } else if (KT == KT_POLYN) {

@@ -494,8 +494,14 @@ float ora_get_info(const float* g, long n, float response) {
     return (response - side_lobe_mean) / (std_ + 1e-7f);      /* 1e-7 is a double literal; float(std)+1e-7 then float division */
 }
 
-/* Array::pow(int) -> std::pow(float,int) -> double pow, rounded back to float [recalled] */
-static inline float pow_int(float x, int p) { return (float)pow((double)x, (double)p); }
+/* Array::pow(int) [recalled, RECALLED.md row 16 -- an OPEN question]: mode 0 (default) = std::pow(float, int) -> double pow,
+ * rounded back to float; mode 1 = the exponent promoted to the array's scalar first (Eigen 3.3's promote_scalar_arg) ->
+ * powf(x, (float)p).  With this image's glibc the two differ by one ulp on 6.6e-4 of the samples (tests/test_toolchain_pins.py);
+ * whoever runs oracle/pin/ against a build of the reference flips the switch if the vectors say so. */
+static int g_pow_mode = 0;
+void ora_set_pow_mode(int mode) { g_pow_mode = mode ? 1 : 0; }
+int ora_get_pow_mode(void) { return g_pow_mode; }
+static inline float pow_int(float x, int p) { return g_pow_mode ? powf(x, (float)p) : (float)pow((double)x, (double)p); }
 
 /* shared tail of the four kernel functions: kernel = kernel / kernel.abs().maxCoeff(); return FFT(kernel) */
 static void normalise_and_fft(ora_ctx* ctx, float* kernel, int rows, int cols, ora_cf32* out) {

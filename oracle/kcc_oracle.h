@@ -89,6 +89,10 @@ void ora_warp  (const float* x, int rows, int cols, float tx, float ty, float de
 
 /* NormalizeDegree utils.cc:173-175 */
 double ora_normalize_degree(double angle_degree);
+/* polynomial kernel's power (correlation_flow.cc:213,223 `Array::pow(int)`): 0 (default) double pow rounded to float, 1 powf with
+ * the exponent promoted to float (oracle/RECALLED.md row 16, an open question: the switch is for whoever can pin it) */
+void ora_set_pow_mode(int mode);
+int  ora_get_pow_mode(void);
 
 /* CorrelationFlow::ComputeIntermedium :89-95 */
 void ora_intermedium(ora_ctx* ctx, const float* image, ora_cf32* fft_result, ora_cf32* fft_polar);

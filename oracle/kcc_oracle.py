@@ -70,6 +70,8 @@ def lib():
         L.ora_rotate.argtypes = [P, C.c_int, C.c_int, C.c_float, P]
         L.ora_normalize_degree.restype = C.c_double
         L.ora_normalize_degree.argtypes = [C.c_double]
+        L.ora_set_pow_mode.argtypes = [C.c_int]
+        L.ora_get_pow_mode.restype = C.c_int
         L.ora_intermedium.argtypes = [P, P, P, P]
         L.ora_estimate_trans.restype = C.c_float
         L.ora_estimate_trans.argtypes = [P, P, P, C.c_int, P, P, P, P, P]

@@ -87,6 +87,26 @@ def test_rotate_gather_bit_exact(geom):
 
 
 @pytest.mark.parametrize("geom", GEOMS)
+def test_gathers_against_opencv_geometry_kats(geom):
+    """the HIP gathers against answers that follow from OpenCV's DOCUMENTED geometry alone (tests/opencv_kats.py), not from the
+    oracle: right-angle RotateArray calls are pure permutations of the normalised image (any fixed-point format gives that),
+    and the four axis rows of polar(fftshift(RemoveZeroComponent(p))) are two-tap blends at exact 1/32-pixel positions
+    (integer-valued p: exact in float32 whatever the order of the blend)."""
+    import opencv_kats as kat
+    cf, orc, _ = _mk(geom)
+    img = synth.canvas(5, geom["H"], geom["W"])[: geom["H"], : geom["W"]]
+    cf.intermedium_u8(img, 0)
+    x = orc.normalize_u8(img)
+    for deg2, q in [(0, 0), (180, 1), (360, 2), (540, 3), (-180, 3), (-360, 2), (720, 0), (-540, 1)]:
+        assert np.array_equal(cf.dbg_rotate(0, deg2), kat.rotate_right_angle(x, q)), "RotateArray(%g deg)" % (deg2 * 0.5)
+    p = np.random.default_rng(13).integers(0, 256, (geom["W"], geom["H"])).astype(np.float32)
+    got = cf.dbg_polar(p)
+    for i, want in kat.polar_axes(kat.remove_zero_fftshift(p), geom["PD"], geom["PC"]).items():
+        assert np.array_equal(got[:, i], want), "warpPolar angle row %d" % i
+    cf.close()
+
+
+@pytest.mark.parametrize("geom", GEOMS)
 def test_intermedium_matches_oracle(geom):
     cf, orc, _ = _mk(geom)
     _, cur = synth.make_pair(4, geom["H"], geom["W"], 3, -5, 2.0)

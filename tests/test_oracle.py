@@ -207,3 +207,25 @@ def test_track_pairs_threads_agree():
     a = ko.track_pairs(cfg, keys, curs, True, nthreads=1)
     b = ko.track_pairs(cfg, keys, curs, True, faithful=True, nthreads=2)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+# ---- OpenCV semantics by construction (tests/opencv_kats.py): right-angle rotations are permutations, the polar transform's
+# ---- four axes are two-tap blends at exact 1/32-pixel positions.  No OpenCV build, no recalled rounding rule involved.
+@pytest.mark.parametrize("geom", [SMALL, FULL])
+def test_rotate_right_angles_are_permutations(geom):
+    import opencv_kats as kat
+    x = np.random.default_rng(11).random((geom["W"], geom["H"]), dtype=np.float32)
+    for deg, q in [(0.0, 0), (90.0, 1), (180.0, 2), (270.0, 3), (-90.0, 3), (-180.0, 2), (360.0, 0), (-270.0, 1), (450.0, 1)]:
+        assert np.array_equal(ko.Oracle.rotate(x, deg), kat.rotate_right_angle(x, q)), "RotateArray(%g deg)" % deg
+
+
+@pytest.mark.parametrize("geom", [SMALL, FULL])
+def test_polar_axes_known_answers(geom):
+    import opencv_kats as kat
+    orc = ko.Oracle(ko.default_config(rotation_divisor=geom["PD"], rotation_channel=geom["PC"]), geom["H"], geom["W"])
+    x = np.random.default_rng(12).integers(0, 256, (geom["W"], geom["H"])).astype(np.float32)
+    got = orc.polar(x)                                          # (PC, PD): got[j, i] = radius j, angle row i
+    for i, want in kat.polar_axes(x, geom["PD"], geom["PC"]).items():
+        assert np.array_equal(got[:, i], want), "warpPolar angle row %d" % i
+    # RemoveZeroComponent + fftshift, restated in numpy, feed the same transform (what ComputeIntermedium does, :93-94)
+    assert np.array_equal(orc.fftshift(orc.remove_zero(x)), kat.remove_zero_fftshift(x))
