@@ -187,6 +187,8 @@ std::vector<float2> plan_table(const PlanDesc& d, bool inv) {
     if (d.np == 2) {
         t.resize((size_t)RL * RF);
         for (int q = 0; q < RL; ++q) for (int k = 0; k < RF; ++k) t[(size_t)q * RF + k] = w((long)q * k, N);
+        // 16 x PR plans (kcc_fft2.h PlanPrime): W_PR^(-+ m), m < PR, behind the pass table
+        for (int m = 0; m < d.prime; ++m) t.push_back(w(m, d.prime));
     } else {
         const int NS = RF * RM;
         t.resize((size_t)RM * RF + (size_t)RL * NS);

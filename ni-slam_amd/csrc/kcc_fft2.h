@@ -122,6 +122,7 @@ template <int N_, int R1_, int R2_, int R3_ = 1>
 struct Plan {
     static constexpr int N = N_, R1 = R1_, R2 = R2_, R3 = R3_;
     static constexpr int NP = R3_ > 1 ? 3 : 2;
+    static constexpr bool PRIME = false;
     static_assert(R1_ * R2_ * R3_ == N_, "plan radices must multiply to N");
     // threads per line = most butterflies in any pass
     static constexpr int T = cmax(cmax(N_ / R1_, N_ / R2_), R3_ > 1 ? N_ / R3_ : 0);
@@ -183,7 +184,37 @@ template <> struct PlanFor<1280> : Plan<1280, KCC_P1280> {};
 template <> struct PlanFor<224> : Plan<224, 14, 16> {};
 template <> struct PlanFor<448> : Plan<448, 7, 8, 8> {};
 template <> struct PlanFor<600> : Plan<600, 24, 25> {};
+// 512 x 512 cameras (round 5; the reference transforms whatever it is given, correlation_flow.cc:53-63): half-rows 256 = 16 x 16
+// (16 threads per line: wave-local chains), lines 512 = 8 x 8 x 8 for the two-plane B kernels and 16 x 32 for the single-plane ones
+#ifndef KCC_P256
+#define KCC_P256 16, 16
+#endif
+#ifndef KCC_P512
+#define KCC_P512 8, 8, 8
+#endif
+template <> struct PlanFor<256> : Plan<256, KCC_P256> {};
+template <> struct PlanFor<512> : Plan<512, KCC_P512> {};
 template <> struct PlanFor<1600> : Plan<1600, 10, 10, 16> {};
+
+// Lines whose length has ONE large prime factor: N = 16 x PR (752 = 16 x 47, the 752 x 480 cameras of the reference's EuRoC-class
+// data sets -- correlation_flow.cc:53-63 plans any size).  The smooth part runs as radix-16 butterflies in registers, the prime part
+// as a direct PR-point DFT whose outputs are shared out over the line's PR threads (thread t computes output k2 = t of all 16
+// sub-transforms: every input is an LDS broadcast read, every term one complex multiply-add with W_PR^(n t mod PR) from a
+// PR-entry table appended to the pass table).  From outside it is a plan whose register arrays are [16] in both directions
+// with stride PR (in: x[j + q PR], out: X[j + q PR], j < PR): the B kernels' loads, stores and pointwise code are unchanged.
+template <int N_, int PR_>
+struct PlanPrime {
+    static constexpr int N = N_, PR = PR_, R1 = 16, R2 = PR_, R3 = 1, NP = 2;
+    static_assert(16 * PR_ == N_, "prime plan: N = 16 x PR");
+    static constexpr bool PRIME = true, SWZ = false, SWZ3 = false;
+    static constexpr int T = PR_;
+    template <bool INV> static constexpr int RF() { return 16; }
+    template <bool INV> static constexpr int RM() { return 1; }
+    template <bool INV> static constexpr int RL() { return 16; }
+    static constexpr int padc(int) { return 0; }
+    static constexpr int EXT = N_ + PR_ + 1;                 // index i lives at i + i / 16
+};
+template <> struct PlanFor<752> : PlanPrime<752, 47> {};
 
 // Plan of the SINGLE-plane B kernels (fwd_abs_inv, the Kzz-cached *_x / solve_cached / zz_inv modes, plain fwd / inv): with one
 // plane per thread a two-pass plan's large radices fit the register budget, and 640 = 20 x 32 (32 threads per line: two passes,
@@ -194,6 +225,10 @@ template <int N> struct PlanAlt : PlanFor<N> {};
 #define KCC_PA640 20, 32
 #endif
 template <> struct PlanAlt<640> : Plan<640, KCC_PA640> {};
+#ifndef KCC_PA512
+#define KCC_PA512 16, 32
+#endif
+template <> struct PlanAlt<512> : Plan<512, KCC_PA512> {};
 // 1280 points: the two-plane kernels (PlanFor) and the single-plane ones want different plans (HD workload, kB<1280,*> ms per 128 pairs:
 // solve_inv / fwd_mul_inv / fwd_abs_inv = 0.437 / 0.385 / 0.284 with 8 x 10 x 16 everywhere, 0.406 / 0.354 / 0.330 with 20 x 8 x 8)
 #ifndef KCC_PA1280
@@ -230,7 +265,7 @@ template <class P, bool INV> struct Dir {
     static constexpr bool S3F = P::SWZ3 && !INV;             // XOR-swizzled exchanges of the 3-pass forward direction
     static constexpr int OFF3 = RM * RF;
     // strided reads i = j + q*M map to phys(j) + q*(M + PADC*M/PAD) when PAD divides M (true for every plan here)
-    static_assert(ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0), "pad must divide the pass strides");
+    static_assert(P::PRIME || (ML % PAD == 0 && (P::NP == 2 || MM % PAD == 0)), "pad must divide the pass strides");
     static constexpr int SL = ML + PADC * (ML / PAD);        // phys stride of last-pass reads
     static constexpr int SM = P::NP == 3 ? MM + PADC * (MM / PAD) : 0;
     __device__ static __forceinline__ unsigned phys(unsigned i) { return i + (unsigned)PADC * (i / (unsigned)PAD); }
@@ -255,12 +290,86 @@ template <bool WAVE> __device__ __forceinline__ void line_sync() {
         __syncthreads();
     }
 }
+// acc + a * w (complex), two packed FMAs
+__device__ __forceinline__ cf2 cmac(cf2 acc, cf2 a, cf2 w) {
+#if KCC_PK_ASM
+    cf2 t, d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));                    // (a.x w.x + acc.x, a.x w.y + acc.y)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(d) : "v"(a), "v"(w), "v"(t));       // (-a.y w.y + t.x, a.y w.x + t.y)
+    return d;
+#else
+    return mk2(acc.x + a.x * w.x - a.y * w.y, acc.y + a.x * w.y + a.y * w.x);
+#endif
+}
+// The chain of a PlanPrime line (see PlanPrime).  N = 16 PR, n = PR n1 + n2, k = k1 + 16 k2:
+//   step A (thread j = n2):  y[k1][n2] = W_N^(n2 k1) * sum_n1 x[PR n1 + n2] W_16^(n1 k1)        -- dft_run<16> + 15 twiddles
+//   step B (thread t = k2):  X[k1 + 16 k2] = sum_n2 y[k1][n2] W_PR^(n2 k2)                      -- PR x 16 multiply-adds, y by broadcast
+//   transpose:               X back into the strided register layout through the same buffer
+// Tables: forward tw[n2 * 16 + k1] = W_N^-(n2 k1), inverse tw[k1 * PR + n2] = W_N^+(n2 k1) (plan_table's two-pass layout for the
+// radices (16, PR)); both followed, at tw[N + m], by W_PR^(-+ m), m < PR.  Index i of the exchange buffer lives at i + i / 16.
+template <class P, bool INV, int NV, bool WAVE>
+__device__ __forceinline__ void fft_chain_prime(cf2 (&vin)[NV][16], cf2 (&vout)[NV][16], unsigned j, cf2* const (&ex)[NV], const cf2* __restrict__ tw) {
+    constexpr int N = P::N, PR = P::PR;
+    const bool act = j < (unsigned)PR;
+    if (act) {
+        cf2 wa[16];
+#pragma unroll
+        for (int k1 = 1; k1 < 16; ++k1) wa[k1] = INV ? tw[k1 * PR + j] : tw[j * 16 + k1];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            dft_run<16, INV>(vin[v]);
+            cf2* w = ex[v] + j * 17;
+            w[0] = vin[v][dft_pos<16>(0)];
+#pragma unroll
+            for (int k1 = 1; k1 < 16; ++k1) w[k1] = cmul(vin[v][dft_pos<16>(k1)], wa[k1]);
+        }
+    }
+    line_sync<WAVE>();
+    cf2 acc[NV][16];
+    if (act) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) acc[v][k1] = ex[v][k1];               // n2 = 0: W = 1
+        const cf2* wp = tw + N;
+        unsigned idx = j;
+#pragma unroll 1
+        for (int n2 = 1; n2 < PR; ++n2) {
+            const cf2 w = wp[idx];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const cf2* y = ex[v] + n2 * 17;
+#pragma unroll
+                for (int k1 = 0; k1 < 16; ++k1) acc[v][k1] = cmac(acc[v][k1], y[k1], w);
+            }
+            idx += j; idx -= idx >= (unsigned)PR ? (unsigned)PR : 0u;
+        }
+    }
+    line_sync<WAVE>();                                       // every y consumed before the buffer takes the spectrum
+    if (act) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int k1 = 0; k1 < 16; ++k1) ex[v][17 * j + k1] = acc[v][k1];      // X[k1 + 16 j]
+    }
+    line_sync<WAVE>();
+    if (act) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { const unsigned i = j + (unsigned)(PR * q); vout[v][q] = ex[v][i + (i >> 4)]; }
+    }
+}
 template <class P, bool INV, int NV, bool WAVE = false, int RFV = 0, int RLV = 0>
 __device__ __forceinline__ void fft_chain(cf2 (&vin)[NV][RFV], cf2 (&vout)[NV][RLV],
                                           unsigned j, cf2* const (&ex)[NV], const cf2* __restrict__ tw) {
     using D = Dir<P, INV>;
     constexpr int RF = D::RF, RL = D::RL, RM = D::RM;
     static_assert(RFV == RF && RLV == RL, "register arrays must match the plan's first / last radix");
+    if constexpr (P::PRIME) {
+        fft_chain_prime<P, INV, NV, WAVE>(vin, vout, j, ex, tw);
+        return;
+    } else {
     // ---- pass 1: radix RF, Ns = 1 (no twiddles); output q of butterfly j goes to phys(j*RF + q) = j*(RF+PADC) + q
     if (j < (unsigned)D::MF) {
 #pragma unroll
@@ -365,6 +474,7 @@ __device__ __forceinline__ void fft_chain(cf2 (&vin)[NV][RFV], cf2 (&vout)[NV][R
 #pragma unroll
             for (int q = 0; q < RL; ++q) vout[v][q] = t[dft_pos<RL>(q)];
         }
+    }
     }
 }
 

@@ -56,7 +56,7 @@ struct Tables {
 };
 
 // radices of the instantiated plan for length n (np = 0 if n is not instantiated)
-struct PlanDesc { int n, np, r[3], t; };      // t: threads per line
+struct PlanDesc { int n, np, r[3], t, prime; };      // t: threads per line; prime: PR of a 16 x PR plan (kcc_fft2.h PlanPrime), else 0
 PlanDesc plan_desc(int n);
 PlanDesc plan_desc_inv(int n);
 PlanDesc plan_desc_alt(int n);   // plan of the single-plane B kernels for line length n   // plan of the spectrum-in A-type kernels for half length n

@@ -21,8 +21,8 @@ namespace kcc {
 // ------------------------------------------------------------------------------------------------
 // instantiated FFT lengths (plans: kcc_fft2.h PlanFor<>)
 // ------------------------------------------------------------------------------------------------
-#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(224) X(240) X(360) X(600)
-#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(448) X(480) X(640) X(1280) X(1600)
+#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(224) X(240) X(256) X(360) X(600)
+#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(448) X(480) X(512) X(640) X(752) X(1280) X(1600)
 
 bool fft_half_supported(int h) {
 #define X(n) if (h == n) return true;
@@ -37,22 +37,22 @@ bool fft_line_supported(int n_) {
     return false;
 }
 PlanDesc plan_desc_inv(int n_) {
-    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
-#define X(n) if (n_ == n) { using P = PlanInv<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0, 0 };
+#define X(n) if (n_ == n) { using P = PlanInv<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; d.prime = P::PRIME ? P::R2 : 0; }
     KCC_HALF_LIST(X)
 #undef X
     return d;
 }
 PlanDesc plan_desc_alt(int n_) {
-    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
-#define X(n) if (n_ == n) { using P = PlanAlt<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0, 0 };
+#define X(n) if (n_ == n) { using P = PlanAlt<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; d.prime = P::PRIME ? P::R2 : 0; }
     KCC_LINE_LIST(X)
 #undef X
     return d;
 }
 PlanDesc plan_desc(int n_) {
-    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0 };
-#define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; }
+    PlanDesc d{ n_, 0, { 1, 1, 1 }, 0, 0 };
+#define X(n) if (n_ == n) { using P = PlanFor<n>; d.np = P::NP; d.r[0] = P::R1; d.r[1] = P::R2; d.r[2] = P::R3; d.t = P::T; d.prime = P::PRIME ? P::R2 : 0; }
     KCC_HALF_LIST(X)
     KCC_LINE_LIST(X)
 #undef X
@@ -871,7 +871,7 @@ template <int HH>
 // (the register prefetch of the next tile needs ~123 VGPRs at 240 points and ~150 at 360: never ask for more waves per
 // SIMD than that leaves room for -- a 128-register cap made the 360-point kernel spill 33 dwords: 0.396 -> 0.331 ms at HD)
 #ifndef KCC_U8_WPS
-#define KCC_U8_WPS(hh) ((hh) >= 360 ? 3 : 4)
+#define KCC_U8_WPS(hh) ((hh) > 240 ? 3 : 4)
 #endif
 __global__ __launch_bounds__(FCfg<HH>::NT, (FCfg<HH>::WPS > KCC_U8_WPS(HH) ? KCC_U8_WPS(HH) : FCfg<HH>::WPS)) void kA_fwd_u8(AArgs a, int tpw) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1266,6 +1266,7 @@ static AArgs base_args(PlaneGeom g, Tables t) {
         case 120: { CALL(120); break; }   \
         case 224: { CALL(224); break; }   \
         case 240: { CALL(240); break; }   \
+        case 256: { CALL(256); break; }   \
         case 360: { CALL(360); break; }   \
         case 600: { CALL(600); break; }   \
         default: break;                   \
@@ -1613,13 +1614,12 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
         if (WLB) __syncthreads();                                     // (wave-local chains hold no workgroup barrier: s_rmax needs one)
         const float rzz = 1.0f / __uint_as_float(a.mzz[zslot]);      // (s_rmax: written before the barriers inside the chain)
         const float rxz = 1.0f / s_rmax[1];
-        static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
         for (int q = 0; q < DF::RL; ++q) {
             const cf2 den = mk2(kz[q].x * rzz + a.lambda, kz[q].y * rzz);
             const cf2 num = mk2(kx[0][q].x * rxz, kx[0][q].y * rxz);
-            const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
+            const float inv = ((DF::ML % 2 == 0 || q % 2 == 0) ? sg : -sg) / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
             const cf2 gg = cmulc(num, den);
             g[0][q] = mk2(gg.x * inv, gg.y * inv);
         }
@@ -1666,14 +1666,13 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             }
         }
         const float rzz = 1.0f / s_rmax[0], rxz = 1.0f / s_rmax[1];   // (wave 0 wrote them before the barriers inside the chains)
-        // ML is even for every plan, so (-1)^l is the same for all q: one sign per thread
-        static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
+        // T[k][l] = (-1)^(k + l), l = j + q ML: one sign per thread when ML is even, alternating with q when it is odd (16 x 47 lines)
         const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
         for (int q = 0; q < DF::RL; ++q) {
             const cf2 den = mk2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
             const cf2 num = mk2(kk[1][q].x * rxz, kk[1][q].y * rxz);
-            const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
+            const float inv = ((DF::ML % 2 == 0 || q % 2 == 0) ? sg : -sg) / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
             const cf2 gg = cmulc(num, den);
             g[0][q] = mk2(gg.x * inv, gg.y * inv);
         }
@@ -1923,13 +1922,12 @@ __global__ __launch_bounds__((RCfg<N, MODE>::NT), (RCfg<N, MODE>::WPS)) void kBr
             __syncthreads();                                          // B1
             if (!nofft) fft_chain<P, false, 2>(vin, kk, j, ex2, twf); else chain_barriers_only<C::CB>();
             const float rzz = 1.0f / s_rmax[2 * (n & 1)], rxz = 1.0f / s_rmax[2 * (n & 1) + 1];   // (the loader wave filed them with the tile)
-            static_assert(DF::ML % 2 == 0, "sign hoisting needs an even last-pass stride");
-            const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
+                const float sg = ((k + (int)j) & 1) ? -1.f : 1.f;
 #pragma unroll
             for (int q = 0; q < DF::RL; ++q) {
                 const cf2 den = mk2(kk[0][q].x * rzz + a.lambda, kk[0][q].y * rzz);
                 const cf2 num = mk2(kk[1][q].x * rxz, kk[1][q].y * rxz);
-                const float inv = sg / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
+                const float inv = ((DF::ML % 2 == 0 || q % 2 == 0) ? sg : -sg) / (den.x * den.x + den.y * den.y);      // IEEE division, as the reference divides (correlation_flow.cc:171)
                 const cf2 gg = cmulc(num, den);
                 g[0][q] = mk2(gg.x * inv, gg.y * inv);
             }
@@ -1996,7 +1994,9 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
         case 320:  { CALL(320);  break; }  \
         case 448:  { CALL(448);  break; }  \
         case 480:  { CALL(480);  break; }  \
+        case 512:  { CALL(512);  break; }  \
         case 640:  { CALL(640);  break; }  \
+        case 752:  { CALL(752);  break; }  \
         case 1280: { CALL(1280); break; }  \
         case 1600: { CALL(1600); break; }  \
         default: break;                    \

@@ -18,9 +18,14 @@ pytestmark = pytest.mark.gpu
 
 # fam: which plane families run the any-size kernels (nik_is_generic: bit 0 image, bit 1 polar) -- the choice is per family, so a
 # 640 x 480 camera with a 720 x 64 polar plane keeps the tiled image kernels
+# (round 5: 752 x 480 and 512 x 512 have tiled plans now -- 752 = 16 x 47 as a radix-16 pass plus a direct 47-point pass shared
+# out over the line's threads, kcc_fft2.h PlanPrime; 256 = 16 x 16, 512 = 8 x 8 x 8 / 16 x 32 -- so each of them runs twice here: on
+# the tiled family it now gets by default (fam 0), and forced onto the any-size family ($NIK_GENERIC=4) as before)
 GEOMS = [
-    pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(1,)), id="752x480"),          # EuRoC-style camera; 752 = 2^4 x 47
-    pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(1,)), id="512x512"),
+    pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(0,)), id="752x480-tiled"),    # EuRoC-style camera; 752 = 2^4 x 47
+    pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(0, 2)), id="512x512-tiled"),
+    pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(1,), force="4"), id="752x480"),
+    pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(1,), force="4"), id="512x512"),
     pytest.param(dict(H=480, W=640, PD=720, PC=64, fam=(2,)), id="polar720x64"),        # config_geekplus.yaml's "64 may work well"
     pytest.param(dict(H=480, W=640, PD=360, PC=240, fam=(2,)), id="polar360x240"),
     pytest.param(dict(H=448, W=448, PD=720, PC=64, fam=(2,)), id="448x448-polar720x64"),  # config_geekplus.yaml with that suggestion
@@ -46,8 +51,16 @@ def test_any_size_geometry_matches_oracle(geom):
     import torch
     H, W, PD, PC = geom["H"], geom["W"], geom["PD"], geom["PC"]
     n = 6
-    N, cf, orc, ocfg = _mk(geom, n)
-    assert cf._L.nik_is_generic(cf._ctx) in geom["fam"]
+    old = os.environ.get("NIK_GENERIC")
+    if geom.get("force") and old is None:
+        os.environ["NIK_GENERIC"] = geom["force"]
+    try:
+        N, cf, orc, ocfg = _mk(geom, n)
+    finally:
+        if geom.get("force") and old is None:
+            os.environ.pop("NIK_GENERIC", None)
+    if old is None:                                              # (under a forced outer run -- the callers' test below -- the mask is the forced one)
+        assert cf._L.nik_is_generic(cf._ctx) in geom["fam"]
     rng = np.random.default_rng(H + W)
     # FFT / IFFT of both plane families against the oracle's
     for which, (rows, cols) in enumerate([(H, W), (PD, PC)]):
