@@ -636,17 +636,22 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
     for (int k = 0; k < nw; ++k) {
         if (k + 1 < nw) {
             // window k+1: its upload was enqueued a whole window ago -- wait for it on the device, start its spectra; window k+2:
-            // start its upload (into the buffer of window k-1, whose push has returned).  That buffer's last READER is the
-            // ComputeIntermedium batch of window k-1 on the compute lanes (enqueued by prefetch / push, possibly still pending
-            // when max_batch is small and a window holds no waited registration): the upload stream waits for the lanes first.
+            // start its upload (into the buffer of window k-1, whose push has returned)
             if ((rc = nik_upload_fence(t->ctx, tk[k + 1]))) return bail(rc);
-            if (k + 2 < nw) {
-                if (k >= 1 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
-                if ((tk[k + 2] = upload(k + 2)) < 0) return bail(tk[k + 2]);
-            }
+            if (k + 2 < nw && (tk[k + 2] = upload(k + 2)) < 0) return bail(tk[k + 2]);
             if ((rc = nik_tracker_prefetch_dev(t, count(k + 1), t->d_up[(k + 1) % 3]))) return bail(rc);
+            // The upload ring reuses a window's buffer three windows later; its last READER is that window's ComputeIntermedium
+            // batch on the compute lanes (just enqueued for window k+1).  Uploads enqueued from here on wait for it on the device.
+            // (Placed HERE, before this iteration's push: a marker behind the push would also cover its look-ahead pose batches,
+            // and the staged uploads of a pageable source would stall the calling thread behind them -- measured 58 k -> 40 k
+            // frames/s.  The intermedium batches are long done when the next upload is enqueued: no wait in practice.)
+            static const bool no_order = getenv("NIK_TRK_NO_UPLOAD_ORDER") != nullptr;      // (A/B switch of tools)
+            if (!no_order && k + 3 < nw && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
         }
         if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return bail(rc);
+        // (window 0 has no prefetch: its ComputeIntermedium batch is enqueued by the push itself, and with max_batch == 1 no waited
+        // registration stands behind it)
+        if (k == 0 && nw > 3 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
     }
     return nik_upload_wait(t->ctx);
 }
