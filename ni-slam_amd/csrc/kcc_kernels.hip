@@ -606,6 +606,12 @@ __device__ __forceinline__ void a_load_pre(cf2* nat, const cf2* __restrict__ tw_
 #ifndef KCC_ROT_WPS
 #define KCC_ROT_WPS 1
 #endif
+// 1: both horizontal taps of a sample row in one 2-byte LDS read (VERDICT r3 / r4 asked).  Measured in round 5: TWICE as slow
+// (kA_fwd<240,rot8> 0.151 -> 0.301 ms, <360,rot8>/1280 0.300 -> 0.526): the 2-byte reads sit at arbitrary byte addresses and the
+// LDS serves a misaligned ds_read_u16 far below the rate of two ds_read_u8.  Off.
+#ifndef KCC_ROT8_U16
+#define KCC_ROT8_U16 0
+#endif
 // SRC_ROT8 geometry: thread (line, j) of the first FFT pass owns dst rows 2(j + q MF), +1 for q < RF, i.e. q selects a band of
 // BR = 2 MF dst rows.  The source of a band x 16-column block is a rotated rectangle; its bounding box (any angle) is at most
 // BW x BH pixels (ceil(hypot(16, BR)) + alignment / tap margins; checked exhaustively over all 0.5-degree angles by
@@ -828,7 +834,15 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
                 for (int h = 0; h < 2; ++h) {
                     const int X = ((h ? xr.y : xr.x) + ad) >> 5, Y = ((h ? yr.y : yr.x) + bd) >> 5;
                     const uint8_t* t = box + (Y >> 5) * R::PITCH + (X >> 5);
+#if KCC_ROT8_U16
+                    // both horizontal taps of a row in ONE LDS read (a 2-byte read at any byte address); the bytes go straight into
+                    // v_cvt_f32_ubyte0 / ubyte1 -- half the LDS instructions of the sampling, same values, twice the time (above)
+                    typedef unsigned short u16u __attribute__((aligned(1)));
+                    const unsigned ta = *reinterpret_cast<const u16u*>(t), tb = *reinterpret_cast<const u16u*>(t + R::PITCH);
+                    r[h] = bilerp(unit_u8(ta & 255u), unit_u8(ta >> 8), unit_u8(tb & 255u), unit_u8(tb >> 8), X & 31, Y & 31);
+#else
                     r[h] = bilerp(unit_u8(t[0]), unit_u8(t[1]), unit_u8(t[R::PITCH]), unit_u8(t[R::PITCH + 1]), X & 31, Y & 31);
+#endif
                 }
                 vin[0][q] = mk2(r[0], r[1]);
             }
