@@ -84,7 +84,7 @@ int  nik_get_dims(const nik_ctx* ctx, int dims[6]);
 /* Which plane families of the context run the any-size kernel family (kcc_generic.hip): a MASK -- bit 0 (1) the image family
  * (H x W), bit 1 (2) the polar family (PD x PC); 0 = both on the tiled kernels, 3 = both on the any-size kernels.  (Test it
  * with `!= 0` or per bit, not `== 1`.)  A family is any-size when its geometry is outside the tiled kernels' instantiated set --
- * half-rows {30,60,120,224,240,256,360,376,600}, lines {80,160,320,448,480,512,640,752,1280,1600}, W and PC multiples of 16,
+ * half-rows {30,60,120,224,240,256,360,384,600}, lines {80,160,320,448,480,512,640,752,848,1024,1280,1600}, W and PC multiples of 16,
  * aspect within 2:1 -- or when $NIK_GENERIC forces it (1 both, 2 polar only, 4 image only).  Same results either way; the
  * any-size family is slower. */
 int  nik_is_generic(const nik_ctx* ctx);

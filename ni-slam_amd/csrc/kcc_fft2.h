@@ -194,6 +194,9 @@ template <> struct PlanFor<600> : Plan<600, 24, 25> {};
 #endif
 template <> struct PlanFor<256> : Plan<256, KCC_P256> {};
 template <> struct PlanFor<512> : Plan<512, KCC_P512> {};
+// 1024 x 768: half-rows 384 = 16 x 24, lines 1024 = 8 x 8 x 16 (two-plane kernels) / 32 x 32 (single-plane ones)
+template <> struct PlanFor<384> : Plan<384, 16, 24> {};
+template <> struct PlanFor<1024> : Plan<1024, 8, 8, 16> {};
 template <> struct PlanFor<1600> : Plan<1600, 10, 10, 16> {};
 
 // Lines whose length has ONE large prime factor: N = 16 x PR (752 = 16 x 47, the 752 x 480 cameras of the reference's EuRoC-class
@@ -215,6 +218,7 @@ struct PlanPrime {
     static constexpr int EXT = N_ + PR_ + 1;                 // index i lives at i + i / 16
 };
 template <> struct PlanFor<752> : PlanPrime<752, 47> {};
+template <> struct PlanFor<848> : PlanPrime<848, 53> {};          // 848 x 480 (depth-camera colour streams): 848 = 16 x 53
 
 // Plan of the SINGLE-plane B kernels (fwd_abs_inv, the Kzz-cached *_x / solve_cached / zz_inv modes, plain fwd / inv): with one
 // plane per thread a two-pass plan's large radices fit the register budget, and 640 = 20 x 32 (32 threads per line: two passes,
@@ -229,6 +233,7 @@ template <> struct PlanAlt<640> : Plan<640, KCC_PA640> {};
 #define KCC_PA512 16, 32
 #endif
 template <> struct PlanAlt<512> : Plan<512, KCC_PA512> {};
+template <> struct PlanAlt<1024> : Plan<1024, 32, 32> {};
 // 1280 points: the two-plane kernels (PlanFor) and the single-plane ones want different plans (HD workload, kB<1280,*> ms per 128 pairs:
 // solve_inv / fwd_mul_inv / fwd_abs_inv = 0.437 / 0.385 / 0.284 with 8 x 10 x 16 everywhere, 0.406 / 0.354 / 0.330 with 20 x 8 x 8)
 #ifndef KCC_PA1280

@@ -21,8 +21,8 @@ namespace kcc {
 // ------------------------------------------------------------------------------------------------
 // instantiated FFT lengths (plans: kcc_fft2.h PlanFor<>)
 // ------------------------------------------------------------------------------------------------
-#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(224) X(240) X(256) X(360) X(600)
-#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(448) X(480) X(512) X(640) X(752) X(1280) X(1600)
+#define KCC_HALF_LIST(X) X(30) X(60) X(120) X(224) X(240) X(256) X(360) X(384) X(600)
+#define KCC_LINE_LIST(X) X(80) X(160) X(320) X(448) X(480) X(512) X(640) X(752) X(848) X(1024) X(1280) X(1600)
 
 bool fft_half_supported(int h) {
 #define X(n) if (h == n) return true;
@@ -1282,6 +1282,7 @@ static AArgs base_args(PlaneGeom g, Tables t) {
         case 240: { CALL(240); break; }   \
         case 256: { CALL(256); break; }   \
         case 360: { CALL(360); break; }   \
+        case 384: { CALL(384); break; }   \
         case 600: { CALL(600); break; }   \
         default: break;                   \
     }
@@ -2011,6 +2012,8 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
         case 512:  { CALL(512);  break; }  \
         case 640:  { CALL(640);  break; }  \
         case 752:  { CALL(752);  break; }  \
+        case 848:  { CALL(848);  break; }  \
+        case 1024: { CALL(1024); break; }  \
         case 1280: { CALL(1280); break; }  \
         case 1600: { CALL(1600); break; }  \
         default: break;                    \

@@ -24,6 +24,8 @@ pytestmark = pytest.mark.gpu
 GEOMS = [
     pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(0,)), id="752x480-tiled"),    # EuRoC-style camera; 752 = 2^4 x 47
     pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(0, 2)), id="512x512-tiled"),
+    pytest.param(dict(H=480, W=848, PD=720, PC=480, fam=(0,)), id="848x480-tiled"),    # 848 = 2^4 x 53: the same prime-factor plan
+    pytest.param(dict(H=768, W=1024, PD=720, PC=480, fam=(0, 2)), id="1024x768-tiled"),
     pytest.param(dict(H=480, W=752, PD=720, PC=480, fam=(1,), force="4"), id="752x480"),
     pytest.param(dict(H=512, W=512, PD=720, PC=480, fam=(1,), force="4"), id="512x512"),
     pytest.param(dict(H=480, W=640, PD=720, PC=64, fam=(2,)), id="polar720x64"),        # config_geekplus.yaml's "64 may work well"
