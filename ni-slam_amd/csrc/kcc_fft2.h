@@ -210,7 +210,7 @@ struct PlanPrime {
     static constexpr int N = N_, PR = PR_, R1 = 16, R2 = PR_, R3 = 1, NP = 2;
     static_assert(16 * PR_ == N_, "prime plan: N = 16 x PR");
     static constexpr bool PRIME = true, SWZ = false, SWZ3 = false;
-    static constexpr int T = PR_;
+    static constexpr int T = PR_ + 1;                        // PR threads carry the line; one more makes the prime pass split evenly
     template <bool INV> static constexpr int RF() { return 16; }
     template <bool INV> static constexpr int RM() { return 1; }
     template <bool INV> static constexpr int RL() { return 16; }
@@ -308,7 +308,7 @@ __device__ __forceinline__ cf2 cmac(cf2 acc, cf2 a, cf2 w) {
 }
 // The chain of a PlanPrime line (see PlanPrime).  N = 16 PR, n = PR n1 + n2, k = k1 + 16 k2:
 //   step A (thread j = n2):  y[k1][n2] = W_N^(n2 k1) * sum_n1 x[PR n1 + n2] W_16^(n1 k1)        -- dft_run<16> + 15 twiddles
-//   step B (thread t = k2):  X[k1 + 16 k2] = sum_n2 y[k1][n2] W_PR^(n2 k2)                      -- PR x 16 multiply-adds, y by broadcast
+//   step B (PR + 1 threads): X[k1 + 16 k2] = sum_n2 y[k1][n2] W_PR^(n2 k2)                      -- two outputs k2 of eight k1 per thread
 //   transpose:               X back into the strided register layout through the same buffer
 // Tables: forward tw[n2 * 16 + k1] = W_N^-(n2 k1), inverse tw[k1 * PR + n2] = W_N^+(n2 k1) (plan_table's two-pass layout for the
 // radices (16, PR)); both followed, at tw[N + m], by W_PR^(-+ m), m < PR.  Index i of the exchange buffer lives at i + i / 16.
@@ -330,32 +330,42 @@ __device__ __forceinline__ void fft_chain_prime(cf2 (&vin)[NV][16], cf2 (&vout)[
         }
     }
     line_sync<WAVE>();
-    cf2 acc[NV][16];
-    if (act) {
+    // step B on PR + 1 threads: thread t owns the outputs k2 = 2 (t / 2), + 1 of HALF the sub-transforms (k1 = 8 (t % 2) + i): every
+    // y it reads feeds two multiply-adds, and a wave-instruction reads only two distinct addresses (broadcast) -- half the LDS
+    // instructions of one output per thread (the LDS pipeline, not the VALU, bounds this pass)
+    static_assert(PR % 2 == 1 && P::T == PR + 1, "prime plan: PR + 1 threads per line");
+    const unsigned kh = (j & 1u) * 8u, ka = (j >> 1) * 2u, kb = ka + 1u;
+    const bool actb = j < (unsigned)(PR + 1), hasb = kb < (unsigned)PR;
+    cf2 acc[NV][2][8];
+    if (actb) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) acc[v][k1] = ex[v][k1];               // n2 = 0: W = 1
+            for (int i = 0; i < 8; ++i) acc[v][0][i] = acc[v][1][i] = ex[v][kh + i];        // n2 = 0: W = 1
         const cf2* wp = tw + N;
-        unsigned idx = j;
+        unsigned ia = ka, ib = hasb ? kb : 0u;
 #pragma unroll 1
         for (int n2 = 1; n2 < PR; ++n2) {
-            const cf2 w = wp[idx];
+            const cf2 wa2 = wp[ia], wb2 = wp[ib];
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
-                const cf2* y = ex[v] + n2 * 17;
+                const cf2* y = ex[v] + n2 * 17 + kh;
 #pragma unroll
-                for (int k1 = 0; k1 < 16; ++k1) acc[v][k1] = cmac(acc[v][k1], y[k1], w);
+                for (int i = 0; i < 8; ++i) { const cf2 yy = y[i]; acc[v][0][i] = cmac(acc[v][0][i], yy, wa2); acc[v][1][i] = cmac(acc[v][1][i], yy, wb2); }
             }
-            idx += j; idx -= idx >= (unsigned)PR ? (unsigned)PR : 0u;
+            ia += ka; ia -= ia >= (unsigned)PR ? (unsigned)PR : 0u;
+            ib += kb; ib -= ib >= (unsigned)PR ? (unsigned)PR : 0u;
         }
     }
     line_sync<WAVE>();                                       // every y consumed before the buffer takes the spectrum
-    if (act) {
+    if (actb) {
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int k1 = 0; k1 < 16; ++k1) ex[v][17 * j + k1] = acc[v][k1];      // X[k1 + 16 j]
+            for (int i = 0; i < 8; ++i) {
+                ex[v][17 * ka + kh + i] = acc[v][0][i];                                   // X[k1 + 16 k2] lives at 17 k2 + k1
+                if (hasb) ex[v][17 * kb + kh + i] = acc[v][1][i];
+            }
     }
     line_sync<WAVE>();
     if (act) {
