@@ -420,13 +420,18 @@ int  nik_tracker_guess_gap(const int32_t* gaps, int n);
 /* ---- measurement ---------------------------------------------------------------------------- */
 
 /* Per-kernel timing with HIP events recorded on nik_stream() around every hot-path launch.
- * bytes = the launch's compulsory HBM traffic (its inputs read once + its outputs written once),
- * summed over launches.  Enabling resets the accumulators; reading synchronises the stream. */
+ * bytes = the launch's NOMINAL traffic (its input planes read once + its output planes written once, whole planes: the
+ * SURVEY 8(d) accounting of that pass), summed over launches.
+ * bytes_design = what the launch is BUILT to move: the nominal planes minus what its symmetry shortcuts leave out (the
+ * Hermitian half of the Kzz kernel plane; the columns |c| <= Rmax + 1 of the zero-phase image) -- the figure a per-kernel
+ * GB/s must be priced on (a kernel priced on bytes it never touches can "exceed" the HBM peak).  bytes_design <= bytes.
+ * Enabling resets the accumulators; reading synchronises the stream. */
 typedef struct {
     char    name[64];     /* kernel<length,mode> */
     double  ms;           /* total device time of the launches */
     int64_t launches;
     double  bytes;
+    double  bytes_design;
 } nik_stage_stat;
 int nik_profile_enable(nik_ctx* ctx, int enable);
 int nik_profile_read(nik_ctx* ctx, nik_stage_stat* out, int cap, int* n);

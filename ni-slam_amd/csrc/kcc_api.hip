@@ -11,6 +11,7 @@
 #include "kcc_kernels.h"
 #include "kcc_generic.h"
 #include "kcc_tables.h"
+#include "kcc_tune.h"
 
 #include <algorithm>
 #include <cmath>
@@ -143,7 +144,7 @@ struct nik_ctx {
     int* rot_tab = nullptr;              // [3][PD][2W+2H] fixed-point warpAffine terms per candidate angle
     std::vector<float> rot_deg;          // [3][PD] degree after normalise/fold (variant 0) or hypothesis angles
     // per-stage HIP-event profiler (nik_profile_enable / nik_profile_read)
-    struct StageStat { std::string name; double ms = 0; long launches = 0; double bytes = 0; };
+    struct StageStat { std::string name; double ms = 0; long launches = 0; double bytes = 0, bytes_design = 0; };
     struct StageRec { int stage; hipEvent_t a, b; };
     bool prof_on = false;
     std::vector<StageStat> prof_stats;
@@ -461,7 +462,8 @@ int ensure_f32_images(nik_ctx* c, Lane& L, int li, int n, const nik_frame* slots
 // ---- stage profiler: brackets one kernel launch with HIP events on the launch stream -----------------
 struct Stage {
     nik_ctx* c; hipStream_t s; int rec = -1;
-    Stage(nik_ctx* c_, Lane& L, const char* name, double bytes) : c(c_), s(L.stream) {
+    // bytes: nominal planes of the pass; design: what the launch is built to move (< 0: the same)
+    Stage(nik_ctx* c_, Lane& L, const char* name, double bytes, double design = -1.0) : c(c_), s(L.stream) {
         // every big kernel of a lane consumes what the previous one produced: alternate the item order so that it starts
         // with the items written last (still in the Infinity Cache)
         if (c->alt_order) { set_launch_reverse(L.flip); L.flip ^= 1; }
@@ -469,7 +471,7 @@ struct Stage {
         int id = -1;
         for (size_t i = 0; i < c->prof_stats.size(); ++i) if (c->prof_stats[i].name == name) { id = (int)i; break; }
         if (id < 0) { c->prof_stats.push_back({}); id = (int)c->prof_stats.size() - 1; c->prof_stats[id].name = name; }
-        c->prof_stats[id].launches += 1; c->prof_stats[id].bytes += bytes;
+        c->prof_stats[id].launches += 1; c->prof_stats[id].bytes += bytes; c->prof_stats[id].bytes_design += design < 0 ? bytes : design;
         nik_ctx::StageRec r; r.stage = id;
         for (hipEvent_t* e : { &r.a, &r.b }) {
             if (!c->prof_pool.empty()) { *e = c->prof_pool.back(); c->prof_pool.pop_back(); }
@@ -537,10 +539,14 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
         }
         // IFFT(|F|) is real and even and the polar gather only reads the inscribed circle: columns |c| <= Rmax + 1 suffice
         const int need = c->zz_half ? std::min(c->H / 2, c->W / 2) + 1 : 0;
-        { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv", b_tag(c, I)).c_str(), n * 3 * Cb(I));
+        // columns of the zero-phase image's half-transformed plane that exist at all (the rest is never written nor read)
+        const double kept = need > 0 ? (double)shifted_columns(c->img.g, need) / c->W : 1.0;
+        // ... and real columns written: each kept column and, for all but column 0 (and W/2), its mirror
+        const double wr_cols = need > 0 ? std::min((double)c->W, 2.0 * shifted_columns(c->img.g, need) - 1.0) : (double)c->W;
+        { Stage st(c, L, kname("kB", c->W, "fwd_abs_inv", b_tag(c, I)).c_str(), n * 3 * Cb(I), n * (2 + kept) * Cb(I));
           launch_B_fwd_abs_inv(s, n, c->img.g, c->img.t, L.tmpA, c->spec_max, c->arena_F, c->img.spec_elems, dst,
                                L.gbuf, c->spec_max, need); }
-        { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)));
+        { Stage st(c, L, kname("kA_inv", c->H / 2, "shifted", a_tag(c, I)).c_str(), n * (Cb(I) + Rb(I)), n * (kept * Cb(I) + Rb(I) * wr_cols / c->W));
           launch_A_inv_shifted(s, n, c->img.g, c->img.t, L.gbuf, c->spec_max, L.splane, c->s_elems, need, c->fuse_fix_zero); }
         // RemoveZeroComponent: inside that kernel (mirrored half-plane form), else a launch of its own
         if (!(need > 0 && c->fuse_fix_zero)) launch_fix_zero(s, n, L.splane, c->s_elems, c->H, c->W);
@@ -606,12 +612,15 @@ void enqueue_estimate(nik_ctx* c, Lane& L, int n, Family& f, bool x_fwd, const f
           launch_B_solve_cached(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, kz, f.spec_elems, mz, z_idx,
                                 c->cfg.lambda, L.gbuf, c->spec_max); }
     } else {
-    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv", b_tag(c, f)).c_str(), n * 4 * Cb(f) + xs_bytes);
+    // Hermitian-half Kzz: of the zz kernel plane only the columns [0, W/2] (whole tiles) are written, transformed and read
+    const double zzk = c->zz_half ? (double)zz_half_columns(f.g) / f.g.cols : 1.0;
+    const double zzs = c->zz_half ? (double)(f.g.cols / 2 + 1) / f.g.cols : 1.0;          // (solve_inv reads columns <= W/2 exactly)
+    { Stage st(c, L, kname("kB", f.g.cols, x_fwd ? "fwd_mul_inv" : "mul_inv", b_tag(c, f)).c_str(), n * 4 * Cb(f) + xs_bytes, n * (3 + zzk) * Cb(f) + xs_bytes);
       launch_B_mul_inv(s, n, f.g, f.t, x_fwd, xsrc, x_stride, x_idx, zsrc, z_stride, z_idx, L.kbuf, item_stride, plane_stride, L.maxbuf,
                        xstore, xstore_stride, xstore_slot, c->zz_half); }
-    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd", a_tag(c, f)).c_str(), n * 4 * Cb(f));
+    { Stage st(c, L, kname("kA_inv", f.g.rows / 2, "kernel_fwd", a_tag(c, f)).c_str(), n * 4 * Cb(f), n * (2 + 2 * zzk) * Cb(f));
       launch_A_inv_kernel_fwd(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, kernel_fn(c), L.maxbuf, L.energy, 0, 2, c->zz_half); }
-    { Stage st(c, L, kname("kB", f.g.cols, "solve_inv", b_tag(c, f)).c_str(), n * 3 * Cb(f));
+    { Stage st(c, L, kname("kB", f.g.cols, "solve_inv", b_tag(c, f)).c_str(), n * 3 * Cb(f), n * (2 + zzs) * Cb(f));
       launch_B_solve_inv(s, n, f.g, f.t, L.kbuf, item_stride, plane_stride, L.maxbuf, c->cfg.lambda, L.gbuf, c->spec_max, c->zz_half); }
     }
     const int nb = argmax_blocks(f.g);
@@ -716,10 +725,30 @@ inline void chunk_of(int n, int nl, int li, int& b, int& e) {
 // batches of 32 are faster on one stream (pyramid workload 16.3 k -> 19.5 k pairs/s)
 inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->active_lanes, n / c->lane_items)); }
 
-int lane_alloc(nik_ctx* c, Lane& L, int nl) {
+// Spatial partitions ($NIK_LANE_CUS, round 6): "k0,k1,..." gives lane i a stream whose kernels only run on k_i CUs, laid
+// behind the CUs of the lanes before it; ONE number k gives every lane the first k CUs.  Mask bit b is CU (b / 8) of XCD b % 8
+// (tools/probes/cumask_probe.hip), so any range of bits that starts and ends on a multiple of 8 keeps all eight XCDs with
+// equal shares -- which the kernels' blockIdx -> XCD affinity relies on.  Unset: plain streams (the whole chip).
+int lane_stream_create(nik_ctx* c, int li, hipStream_t* s) {
+    const char* e = kcc::tune_env("NIK_LANE_CUS");
+    if (!e || !*e) { HIP_TRY(c, hipStreamCreateWithFlags(s, hipStreamNonBlocking)); return NIK_OK; }
+    std::vector<int> k;
+    for (const char* p = e; *p;) { k.push_back(atoi(p)); while (*p && *p != ',') ++p; if (*p == ',') ++p; }
+    int first = 0, count = k[0];
+    if (k.size() > 1) { for (int i = 0; i < li && i < (int)k.size(); ++i) first += k[i]; count = k[std::min(li, (int)k.size() - 1)]; if (li >= (int)k.size()) first = 0; }
+    hipDeviceProp_t prop; HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    const int ncu = prop.multiProcessorCount;
+    if (count <= 0 || first + count > ncu || (first % 8) || (count % 8)) return fail(c, NIK_ERR_INVALID_ARG, "NIK_LANE_CUS: lane %d would own CUs [%d, %d) of %d (multiples of 8 only)", li, first, first + count, ncu);
+    std::vector<uint32_t> mask((ncu + 31) / 32, 0u);
+    for (int b = first; b < first + count; ++b) mask[b >> 5] |= 1u << (b & 31);
+    HIP_TRY(c, hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()));
+    return NIK_OK;
+}
+
+int lane_alloc(nik_ctx* c, Lane& L, int nl, int li) {
     L.cap_items = c->max_items;
     L.seen.assign(nl, 0); L.seen_tail.assign(nl, 0);
-    HIP_TRY(c, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+    { const int rc = lane_stream_create(c, li, &L.stream); if (rc) return rc; }
     HIP_TRY(c, hipEventCreateWithFlags(&L.write_ev, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&L.tail_ev, hipEventDisableTiming));
     HIP_TRY(c, hipMalloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
@@ -766,7 +795,7 @@ void lane_free(Lane& L) {
 int ensure_lanes(nik_ctx* c, int n) {
     for (int li = 0; li < n && li < (int)c->lanes.size(); ++li)
         if (!c->lanes[li].stream) {
-            int rc = lane_alloc(c, c->lanes[li], (int)c->lanes.size());
+            int rc = lane_alloc(c, c->lanes[li], (int)c->lanes.size(), li);
             if (rc) return rc;
             if (c->up_fenced >= 0) HIP_TRY(c, hipStreamWaitEvent(c->lanes[li].stream, c->up_ev[c->up_fenced & 3], 0));   // nik_upload_fence
         }
@@ -840,12 +869,12 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     TRY_C(hipMalloc(&c->arena_MzP, sizeof(unsigned) * max_frames));
     c->slot_kzz.assign(max_frames, 0);
     if (const char* e = getenv("NIK_KZZ_CACHE")) c->kzz_cache = atoi(e) != 0;
-    if (const char* e = getenv("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
-    if (const char* e = getenv("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
-    if (const char* e = getenv("NIK_ALT_ORDER")) c->alt_order = atoi(e) != 0;
-    if (const char* e = getenv("NIK_FUSE_FIX_ZERO")) c->fuse_fix_zero = atoi(e) != 0;
-    if (const char* e = getenv("NIK_CHUNK")) c->chunk_pairs = std::max(0, atoi(e));
-    if (const char* e = getenv("NIK_LANE_ITEMS")) c->lane_items = std::max(1, atoi(e));
+    if (const char* e = kcc::tune_env("NIK_FUSE_POLAR")) c->fuse_polar = atoi(e) != 0;
+    if (const char* e = kcc::tune_env("NIK_ZZ_HALF")) c->zz_half = atoi(e) != 0;
+    if (const char* e = kcc::tune_env("NIK_ALT_ORDER")) c->alt_order = atoi(e) != 0;
+    if (const char* e = kcc::tune_env("NIK_FUSE_FIX_ZERO")) c->fuse_fix_zero = atoi(e) != 0;
+    if (const char* e = kcc::tune_env("NIK_CHUNK")) c->chunk_pairs = std::max(0, atoi(e));
+    if (const char* e = kcc::tune_env("NIK_LANE_ITEMS")) c->lane_items = std::max(1, atoi(e));
     if (const char* e = getenv("NIK_GRAPH")) c->graph_max = std::max(0, atoi(e));
     c->slot_kind.assign(max_frames, 0);
     c->slot_ready.assign(max_frames, 0); c->slot_lane.assign(max_frames, -1); c->slot_seq.assign(max_frames, 0); c->slot_rd.assign((size_t)max_frames * 4, 0);
@@ -858,7 +887,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     // from the ones that work, and a context that is switched to one stream right after creation (the pyramid's levels)
     // should never pay for the others
     c->lanes.resize(nl); c->active_lanes = nl;
-    if ((rc = lane_alloc(c, c->lanes[0], nl))) return bail(rc);
+    if ((rc = lane_alloc(c, c->lanes[0], nl, 0))) return bail(rc);
     TRY_C(hipMalloc(&c->d_u8, (size_t)H * W));
     TRY_C(hipMalloc(&c->d_scratch, sizeof(float) * std::max(c->img.real_elems, 2 * c->spec_max) * 2));
     if (c->generic) { c->fuse_polar = false; c->kzz_cache = false; c->graph_max = 0; }    // (the any-size family has no fused / cached / captured forms)
@@ -1772,7 +1801,7 @@ int nik_profile_read(nik_ctx* c, nik_stage_stat* out, int cap, int* n) {
     for (int i = 0; i < *n && i < cap && out; ++i) {
         memset(&out[i], 0, sizeof(out[i]));
         strncpy(out[i].name, c->prof_stats[i].name.c_str(), sizeof(out[i].name) - 1);
-        out[i].ms = c->prof_stats[i].ms; out[i].launches = c->prof_stats[i].launches; out[i].bytes = c->prof_stats[i].bytes;
+        out[i].ms = c->prof_stats[i].ms; out[i].launches = c->prof_stats[i].launches; out[i].bytes = c->prof_stats[i].bytes; out[i].bytes_design = c->prof_stats[i].bytes_design;
     }
     return NIK_OK;
 }

@@ -14,6 +14,7 @@
 // the transposed passes are uncoalesced).  Spectra keep the k-major layout, so the frame store, export / import, the tracker,
 // the map and the group code see no difference.
 #include "kcc_generic.h"
+#include "kcc_tune.h"
 
 #include <algorithm>
 #include <cmath>
@@ -198,7 +199,7 @@ void launch_fft_lines(hipStream_t s, int n_items, GFArgs a, bool inv) {
     // points per workgroup left one workgroup per CU and bought nothing); one line for the longest lengths
     const size_t per_line = (size_t)2 * n * sizeof(cf2);
     const size_t tw_bytes = (size_t)n * sizeof(cf2);
-    static const int want_tw = getenv("NIK_G_TWLDS") ? atoi(getenv("NIK_G_TWLDS")) : 1;
+    static const int want_tw = kcc::tune_env("NIK_G_TWLDS") ? atoi(kcc::tune_env("NIK_G_TWLDS")) : 1;
     a.tw_lds = (want_tw && tw_bytes + 2 * per_line <= (size_t)48 * 1024) ? 1 : 0;      // the table next to at least two lines
     int waves = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)(48 * 1024) - (a.tw_lds ? tw_bytes : 0)) / per_line));
     if (a.mode == GF_C2C) waves = std::min(waves, 4);        // (contiguous lines: nothing to gain from a wider workgroup)

@@ -148,6 +148,11 @@ int  argmax_blocks(PlaneGeom g);
 // (float bits); the ridge solve folds them.  kfwd_parts: parts per plane (half: the Hermitian-half zz plane)
 enum { KCC_MAXPARTS = 1024 };
 int  kfwd_parts(PlaneGeom g, bool half);
+// column counts of the symmetry shortcuts (the stage profiler prices the launches on them):
+// zz_half_columns: columns [0, W/2] rounded up to whole kernel_fwd tiles -- what is kept of the Hermitian Kzz kernel plane;
+// shifted_columns: columns [0, min(W/2, need)] rounded up to whole tiles -- what the even-half inverse row pass of the zero-phase image reads
+int  zz_half_columns(PlaneGeom g);
+int  shifted_columns(PlaneGeom g, int need);
 
 // ---- B-type: contiguous spectrum lines along `cols` ----
 void launch_B_fwd(hipStream_t s, int n_items, PlaneGeom g, Tables t, const float2* src, size_t src_stride,

@@ -11,6 +11,7 @@
 #include "kcc_kernels.h"
 #include "kcc_fft2.h"
 #include "kcc_pointwise.h"
+#include "kcc_tune.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -75,7 +76,7 @@ PlanDesc plan_desc(int n_) {
 // 1 no loads / gathers, 2 no stores, 4 no FFT, 8 exit at once (dispatch cost only), 16 no gather staging, 32 no gather sampling,
 // 64 no u8 frame-store copy.  The release library contains none of it (ABL() is a compile-time false).
 #ifdef KCC_ABLATE
-static int ablate_flags() { static const int f = getenv("NIK_ABLATE") ? atoi(getenv("NIK_ABLATE")) : 0; return f; }
+static int ablate_flags() { static const int f = tune_env("NIK_ABLATE") ? atoi(tune_env("NIK_ABLATE")) : 0; return f; }
 #define ABL(a, bit) (((a).ablate & (bit)) != 0)
 #else
 static int ablate_flags() { return 0; }
@@ -881,6 +882,9 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
 #ifndef KCC_U8_COPY_ROWS
 #define KCC_U8_COPY_ROWS 0
 #endif
+#if !defined(KCC_ABLATE) && (KCC_ROT8_U16 || KCC_U8_COPY_ROWS)
+#error "KCC_ROT8_U16 / KCC_U8_COPY_ROWS are measured no-go forms: tuning library (-DKCC_ABLATE) only"
+#endif
 template <int HH>
 // (the register prefetch of the next tile needs ~123 VGPRs at 240 points and ~150 at 360: never ask for more waves per
 // SIMD than that leaves room for -- a 128-register cap made the 360-point kernel spill 33 dwords: 0.396 -> 0.331 ms at HD)
@@ -1243,7 +1247,7 @@ template <int HH, int EPI, int LXO = 0> static void launchA_inv_t(hipStream_t s,
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kA_inv<HH, EPI, LXO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)C::BYTES) == hipSuccess);
     (void)big_lds;
 #ifdef KCC_ABLATE
-    static const size_t lds_pad = getenv("NIK_LDS_PAD_A") ? (size_t)atoi(getenv("NIK_LDS_PAD_A")) : 0;   // occupancy experiments
+    static const size_t lds_pad = tune_env("NIK_LDS_PAD_A") ? (size_t)atoi(tune_env("NIK_LDS_PAD_A")) : 0;   // occupancy experiments
     hipLaunchKernelGGL((kA_inv<HH, EPI, LXO>), grid, block, std::min<size_t>(C::BYTES + lds_pad, 65536), s, a);
     return;
 #endif
@@ -1258,7 +1262,7 @@ template <int HH> static void polar_launch(hipStream_t s, int n_items, const AAr
     constexpr int RF = Dir<typename FCfg<HH>::P, false>::RF;
     AArgs a = a_in;
     // tiles per group: the largest divisor of the tile count that is <= the wanted group size ($NIK_POLAR_GROUP; 1 = tile-major)
-    static const int want = getenv("NIK_POLAR_GROUP") ? std::max(1, atoi(getenv("NIK_POLAR_GROUP"))) : KCC_POLAR_GROUP;
+    static const int want = tune_env("NIK_POLAR_GROUP") ? std::max(1, atoi(tune_env("NIK_POLAR_GROUP"))) : KCC_POLAR_GROUP;
     const int tiles = a.cols / FCfg<HH>::LX;
     int G = std::min(want, tiles);
     while (tiles % G) --G;
@@ -1316,7 +1320,7 @@ void launch_A_fwd_polar(hipStream_t s, int n_items, PlaneGeom g, Tables t, const
 template <int HH> static void launchA_fwd_u8_t(hipStream_t s, int n_items, AArgs a) {
     a.n_items = n_items;
     const int nbx = a.cols / FCfg<HH>::LX;
-    static const int tpw_env = [] { const char* e = getenv("NIK_U8_TPW"); return e ? atoi(e) : 0; }();
+    static const int tpw_env = [] { const char* e = tune_env("NIK_U8_TPW"); return e ? atoi(e) : 0; }();
     int tpw = tpw_env > 0 ? tpw_env : KCC_U8_TPW;
     while (tpw > 1 && nbx % tpw) --tpw;                      // tiles per workgroup must divide the tiles of an image
     dim3 grid((nbx / tpw) * n_items), block(FCfg<HH>::NT);
@@ -1698,6 +1702,8 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
     }
 }
 
+// (the ring form is a measured no-go for speed -- DESIGN 4.5 -- and is compiled into the TUNING library only: -DKCC_ABLATE)
+#ifdef KCC_ABLATE
 // ------------------------------------------------------------------------------------------------
 // B-type kernels, ring form (round 5): persistent workgroups fed by a loader wave through LDS-DMA
 // ------------------------------------------------------------------------------------------------
@@ -1733,6 +1739,7 @@ __host__ __device__ constexpr int ring_lk(int n, int mode) {
     return n == 480 ? KCC_RING_LK480 : n == 640 ? (ring_two_plane(mode) ? KCC_RING_LK640 : KCC_RING_LK640A) : n == 1280 ? KCC_RING_LK1280 : 0;
 }
 template <int N, int MODE> struct RCfg {
+    static_assert(!PlanFor<N>::PRIME, "ring form: the loader wave mirrors the barrier count of the 2- / 3-pass chains only (fft_chain_prime runs 3 line_syncs)");
     static constexpr bool ALT = !ring_two_plane(MODE);
     using P = typename std::conditional<ALT, PlanAlt<N>, PlanFor<N>>::type;
     static constexpr int T = P::T;
@@ -1959,8 +1966,8 @@ __global__ __launch_bounds__((RCfg<N, MODE>::NT), (RCfg<N, MODE>::WPS)) void kBr
 #ifndef KCC_RING_DEFAULT
 #define KCC_RING_DEFAULT 0
 #endif
-static int ring_mask() { static const int m = getenv("NIK_RING") ? atoi(getenv("NIK_RING")) : KCC_RING_DEFAULT; return m; }
-static int ring_wgpc() { static const int m = getenv("NIK_RING_WGPC") ? atoi(getenv("NIK_RING_WGPC")) : 0; return m; }
+static int ring_mask() { static const int m = tune_env("NIK_RING") ? atoi(tune_env("NIK_RING")) : KCC_RING_DEFAULT; return m; }
+static int ring_wgpc() { static const int m = tune_env("NIK_RING_WGPC") ? atoi(tune_env("NIK_RING_WGPC")) : 0; return m; }
 template <int N, int MODE> static bool launchBr_t(hipStream_t s, int n_items, const BArgs& a_in) {
     if constexpr (ring_mode_ok(MODE) && ring_lk(N, MODE) > 0) {
         using C = RCfg<N, MODE>;
@@ -1970,7 +1977,7 @@ template <int N, int MODE> static bool launchBr_t(hipStream_t s, int n_items, co
         if (C::ALT) { a.tw_f = a.twA_f; a.tw_i = a.twA_i; }
         static const int cus = [] { int dev = 0; hipDeviceProp_t p; if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256; return p.multiProcessorCount; }();
         const int wgpc = ring_wgpc() > 0 ? std::min(ring_wgpc(), C::WGPC) : C::WGPC;
-        static const bool force = getenv("NIK_RING_FORCE") && atoi(getenv("NIK_RING_FORCE"));   // tests: ring form at every batch size
+        static const bool force = tune_env("NIK_RING_FORCE") && atoi(tune_env("NIK_RING_FORCE"));   // tests: ring form at every batch size
         const int total = ((a.hr + C::LK - 1) / C::LK) * n_items;
         int slots = wgpc * cus;
         if (total < 2 * slots) { if (!force) return false; slots = std::max(1, std::min(slots, (total + 1) / 2)); }
@@ -1983,6 +1990,9 @@ template <int N, int MODE> static bool launchBr_t(hipStream_t s, int n_items, co
         return false;
     }
 }
+#else
+template <int N, int MODE> static bool launchBr_t(hipStream_t, int, const BArgs&) { return false; }
+#endif
 
 template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, const BArgs& a_in) {
     if (launchBr_t<N, MODE>(s, n_items, a_in)) return;
@@ -1995,7 +2005,7 @@ template <int N, int MODE> static void launchB_t(hipStream_t s, int n_items, con
         (hipFuncSetAttribute(reinterpret_cast<const void*>(&kB<N, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BYTES) == hipSuccess);
     (void)big_lds;
 #ifdef KCC_ABLATE
-    static const size_t lds_pad = getenv("NIK_LDS_PAD_B") ? (size_t)atoi(getenv("NIK_LDS_PAD_B")) : 0;   // occupancy experiments
+    static const size_t lds_pad = tune_env("NIK_LDS_PAD_B") ? (size_t)atoi(tune_env("NIK_LDS_PAD_B")) : 0;   // occupancy experiments
     hipLaunchKernelGGL((kB<N, MODE>), grid, block, std::min<size_t>(BYTES + lds_pad, 65536), s, a);
     return;
 #endif

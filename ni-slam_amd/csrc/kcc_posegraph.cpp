@@ -16,6 +16,7 @@
 // Per keyframe insertion with >= 2 loop matches, not per frame: host code, double precision.
 #include "../../include/nislam_kcc.h"
 #include "kcc_posegraph_dev.h"
+#include "kcc_tune.h"
 
 #include <algorithm>
 #include <cmath>
@@ -270,7 +271,7 @@ static int optimize(int device, int n_poses, const int32_t* ids, double* poses, 
         if (!dev) return NIK_ERR_HIP;
     }
     struct Guard { kcc_pg::DevProblem* d; ~Guard() { kcc_pg::dev_destroy(d); } } guard{ dev };
-    const bool host_solve = getenv("NIK_PG_HOST_SOLVE") && atoi(getenv("NIK_PG_HOST_SOLVE")) != 0;
+    const bool host_solve = kcc::tune_env("NIK_PG_HOST_SOLVE") && atoi(kcc::tune_env("NIK_PG_HOST_SOLVE")) != 0;
     // linearise at xs: residual cost, and (want_normal) the Gauss-Newton blocks into N
     std::vector<double> r_, J_;
     auto linearize = [&](const std::vector<double>& xs, double& cost_out, Normal* N) -> bool {

@@ -3,6 +3,7 @@
 // conversions (src/camera.cc:148-211), in double precision exactly as the reference, on top of the C ABI.
 // No GPU code here; every registration goes through nik_track_batch_dev / nik_pose_batch.
 #include "../../include/nislam_kcc.h"
+#include "kcc_tune.h"
 
 #include <algorithm>
 #include <cmath>
@@ -352,8 +353,8 @@ int nik_tracker_create(nik_ctx* ctx, const nik_tracker_config* cfg, nik_tracker*
     nik_tracker* t = new nik_tracker();
     t->ctx = ctx; t->cfg = *cfg; t->H = dims[0]; t->W = dims[1]; t->max_batch = dims[4]; t->max_frames = dims[5];
     for (int s = t->max_frames - 1; s >= 0; --s) t->free_slots.push_back(s);          // pop_back hands out 0, 1, 2, ...
-    if (const char* e = getenv("NIK_TRK_DEPTH")) t->la_depth = std::max(1, std::min(4, atoi(e)));
-    if (const char* e = getenv("NIK_TRK_FLIGHT")) t->la_room = std::max(0, atoi(e));
+    if (const char* e = kcc::tune_env("NIK_TRK_DEPTH")) t->la_depth = std::max(1, std::min(4, atoi(e)));
+    if (const char* e = kcc::tune_env("NIK_TRK_FLIGHT")) t->la_room = std::max(0, atoi(e));
     (void)nik_set_lane_rotation(ctx, 1);     // look-ahead batches run side by side on the context's streams ...
     (void)nik_set_call_depth(ctx, 4);        // ... and none of them makes the host wait for an older one when it is enqueued
     *out = t;
@@ -645,7 +646,7 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
             // (Placed HERE, before this iteration's push: a marker behind the push would also cover its look-ahead pose batches,
             // and the staged uploads of a pageable source would stall the calling thread behind them -- measured 58 k -> 40 k
             // frames/s.  The intermedium batches are long done when the next upload is enqueued: no wait in practice.)
-            static const bool no_order = getenv("NIK_TRK_NO_UPLOAD_ORDER") != nullptr;      // (A/B switch of tools)
+            static const bool no_order = kcc::tune_env("NIK_TRK_NO_UPLOAD_ORDER") != nullptr;      // (A/B switch of tools)
             if (!no_order && k + 3 < nw && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
         }
         if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return bail(rc);

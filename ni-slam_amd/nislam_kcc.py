@@ -93,7 +93,7 @@ class NikLoopResult(C.Structure):
 
 
 class NikStageStat(C.Structure):
-    _fields_ = [("name", C.c_char * 64), ("ms", C.c_double), ("launches", C.c_int64), ("bytes", C.c_double)]
+    _fields_ = [("name", C.c_char * 64), ("ms", C.c_double), ("launches", C.c_int64), ("bytes", C.c_double), ("bytes_design", C.c_double)]
 
 
 class NikError(RuntimeError):
@@ -549,7 +549,7 @@ class CorrelationFlow:
         out = (NikStageStat * 64)()
         n = C.c_int(0)
         self._chk(self._L.nik_profile_read(self._ctx, C.cast(out, C.c_void_p), 64, C.addressof(n)))
-        return [dict(name=out[i].name.decode(), ms=out[i].ms, launches=out[i].launches, bytes=out[i].bytes)
+        return [dict(name=out[i].name.decode(), ms=out[i].ms, launches=out[i].launches, bytes=out[i].bytes, bytes_design=out[i].bytes_design)
                 for i in range(min(n.value, 64))]
 
     # ---- debug taps --------------------------------------------------------------------------

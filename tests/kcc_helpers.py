@@ -102,3 +102,27 @@ def imposed_rerun(ocfg, H, W, key_img, cur_img, not_large_rotation):
         _, xp = o.intermedium(x)
         return o.compute_pose(kf, x, kp, xp, not_large_rotation)
     return rerun
+
+
+def tuning_lib():
+    """path of the tuning library (ni-slam_amd/build.py build_tuning(): -DKCC_ABLATE, every laboratory switch of kcc_tune.h alive)"""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return os.path.join(root, "ni-slam_amd", "libnislam_kcc_hip_tune.so")
+
+
+def run_under_tuning_lib(pytest_args, extra_env=None, timeout=850):
+    """Run pytest in a subprocess whose binding loads the TUNING library ($NIK_LIB): the release library has no laboratory
+    switches, so tests of a non-default form ($NIK_RING, $NIK_FUSE_FIX_ZERO=0 ...) run there.  The tuning library is built by
+    __graft_entry__.build(); its absence is a failure, not a skip."""
+    import os
+    import subprocess
+    import sys
+    lib = tuning_lib()
+    assert os.path.exists(lib), "tuning library missing: run __graft_entry__.build() (ni-slam_amd/build.py --tune)"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NIK_LIB=lib, NIK_UNDER_TUNING_LIB="1", **(extra_env or {}))
+    p = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x"] + list(pytest_args), cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout, p.stdout[-2000:]
+    return p.stdout

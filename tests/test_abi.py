@@ -97,3 +97,32 @@ def test_cpp_adaptor_runs(lib_path, tmp_path):
     for size in (["60", "80"], ["480", "640"]):
         out = subprocess.run([exe] + size, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0 and "ADAPTOR TEST OK" in out.stdout, out.stdout + out.stderr
+
+
+RELEASE_ENV = {"NIK_STREAMS", "NIK_KZZ_CACHE", "NIK_GENERIC", "NIK_GRAPH", "NIK_GROUP_INIT_TIMEOUT", "NIK_GROUP_FORCE_RCCL"}
+
+
+def _env_names(path):
+    data = open(path, "rb").read()
+    return set(m.decode() for m in re.findall(rb"(?<![A-Z_0-9])NIK_[A-Z][A-Z_0-9]+(?=\x00)", data)) - {"NIK_OK"}
+
+
+def test_release_library_carries_no_laboratory_switches(lib_path):
+    """the release library reads only the switches a caller needs; ablation flags, LDS padding, the ring-form
+    B kernels and the alternative fusion / ordering forms exist in the tuning library (-DKCC_ABLATE) alone -- in the release
+    binary not even their names (kcc_tune.h: tune_env() folds to nullptr)."""
+    names = {n for n in _env_names(lib_path) if not n.startswith("NIK_ERR")}
+    assert names <= RELEASE_ENV, "laboratory switches in the release library: %s" % sorted(names - RELEASE_ENV)
+    src = "".join(open(os.path.join(PKG, "csrc", f), errors="ignore").read() for f in os.listdir(os.path.join(PKG, "csrc"))
+                  if f.endswith((".hip", ".cpp", ".h")))
+    plain = set(re.findall(r'(?<![a-z_])getenv\("(NIK_[A-Z_0-9]+)"\)', src))
+    assert plain <= RELEASE_ENV | {"NIK_ABLATE"} and "kBr" not in os.popen("nm -C %s | grep ' kcc::kBr' | head -1" % lib_path).read()
+
+
+def test_tuning_library_has_the_same_abi(lib_path):
+    build = load_module("nislam_build", os.path.join(PKG, "build.py"))
+    tune = build.build_tuning()
+    T = ctypes.CDLL(tune)
+    for n in _declared():
+        assert hasattr(T, n), "tuning library lacks %s" % n
+    assert {"NIK_ABLATE", "NIK_RING", "NIK_LANE_CUS", "NIK_FUSE_FIX_ZERO"} <= _env_names(tune)

@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 BITS="${@:-0 3 4 7 15}"
 for a in $BITS; do
-  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_abl.so NIK_ABLATE=$a python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached > gpurun_out/abl$a.json 2>gpurun_out/abl$a.err || echo "FAIL $a"
+  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_tune.so NIK_ABLATE=$a python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached > gpurun_out/abl$a.json 2>gpurun_out/abl$a.err || echo "FAIL $a"
 done
 python - $BITS <<PY
 import json, sys

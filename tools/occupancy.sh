@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 for v in "B 0" "B 6000" "B 18000" "B 28000" "A 0" "A 3000" "A 16000" "A 26000"; do
   set -- $v
-  env NIK_LDS_PAD_$1=$2 NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_abl.so NIK_ABLATE=0 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached > gpurun_out/occ_$1_$2.json 2>gpurun_out/occ.err || echo FAIL $v
+  env NIK_LDS_PAD_$1=$2 NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_tune.so NIK_ABLATE=0 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached > gpurun_out/occ_$1_$2.json 2>gpurun_out/occ.err || echo FAIL $v
 done
 python - <<PY
 import json

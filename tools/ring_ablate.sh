@@ -3,7 +3,7 @@
 # stores (arithmetic + LDS only) / 1 no loads / 2 no stores, for $NIK_RING 0 and 7
 cd ${GRAFT_REPO_ROOT:-/root/repo}; mkdir -p gpurun_out
 for r in 0 7; do for a in 0 4 3 1 2; do
-  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_abl.so NIK_RING=$r NIK_ABLATE=$a timeout 300 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached --no-live-prof > gpurun_out/rabl_${r}_$a.json 2>gpurun_out/rabl_${r}_$a.err || echo "FAIL $r $a"
+  NIK_LIB=$PWD/ni-slam_amd/libnislam_kcc_hip_tune.so NIK_RING=$r NIK_ABLATE=$a timeout 300 python bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-cached --no-live-prof > gpurun_out/rabl_${r}_$a.json 2>gpurun_out/rabl_${r}_$a.err || echo "FAIL $r $a"
 done; done
 python - <<PY
 import json
