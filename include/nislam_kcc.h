@@ -383,6 +383,9 @@ enum { NIK_PG_CONVERGENCE = 0, NIK_PG_NO_CONVERGENCE = 1, NIK_PG_FAILURE = 2, NI
 typedef struct {
     int32_t termination;             /* NIK_PG_*: NO_CONVERGENCE = max_iterations reached (still usable)          */
     int32_t iterations, successful_steps;
+    int32_t inexact_solves;          /* device solves that hit the PCG iteration limit before its tolerance (their step is
+                                      * still tried on its merits by the trust-region test); 0 on the host path.  Occupies
+                                      * what was padding: size and the other offsets are unchanged                         */
     double  initial_cost, final_cost;   /* 0.5 * sum of squared residuals, as Ceres reports                       */
 } nik_pg_summary;
 /* poses: n_poses x (x, y, yaw), updated in place; ids: their frame ids (must contain 0); max_iterations <= 0: 300. */

@@ -93,10 +93,23 @@ static void rccl_load(Rccl& r) {
 // block for good: a benchmark driver would then see a timeout instead of a line.  The call runs on a helper thread; past
 // $NIK_GROUP_INIT_TIMEOUT seconds (default 90) the group creation FAILS with a clear message (the caller falls back or
 // reports), and the helper thread -- still inside RCCL -- is left detached with its own copy of everything it touches.
-struct InitJob { std::mutex mu; std::condition_variable cv; bool done = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; std::string hip_err; };
-static int comm_init_rank_deadline(int device, int world, const ncclUniqueId& u, int rank, ncclComm_t* out, std::string& err) {
+// A communicator that forms AFTER its creator gave up (the peers arrived late) has an abandoned rank in it: the helper destroys
+// it at once (ncclCommAbort where the library has it, else ncclCommDestroy), so that the peers' first collective fails fast
+// instead of waiting for a rank that will never call it, and nothing leaks.
+struct InitJob { std::mutex mu; std::condition_variable cv; bool done = false, abandoned = false; ncclResult_t res = ncclSuccess; ncclComm_t comm = nullptr; std::string hip_err; };
+// $NIK_GROUP_INIT_TIMEOUT in seconds: a number > 0; "0" = no limit (explicitly); anything unparsable = the 90 s default
+// (atof() of garbage is 0 and would have switched the guard off silently)
+static double init_timeout_seconds() {
     const char* e = getenv("NIK_GROUP_INIT_TIMEOUT");
-    const double limit = e ? atof(e) : 90.0;
+    if (!e || !*e) return 90.0;
+    char* end = nullptr;
+    const double v = strtod(e, &end);
+    while (end && (*end == ' ' || *end == '\t')) ++end;
+    if (end == e || (end && *end) || !(v >= 0.0)) return 90.0;
+    return v;
+}
+static int comm_init_rank_deadline(int device, int world, const ncclUniqueId& u, int rank, ncclComm_t* out, std::string& err) {
+    const double limit = init_timeout_seconds();
     auto job = std::make_shared<InitJob>();
     std::thread([job, device, world, u, rank] {
         ncclComm_t c = nullptr; ncclResult_t r = ncclSuccess; std::string he;
@@ -104,12 +117,19 @@ static int comm_init_rank_deadline(int device, int world, const ncclUniqueId& u,
         if (h != hipSuccess) he = std::string("hipSetDevice: ") + hipGetErrorString(h);
         else r = rccl().CommInitRank(&c, world, u, rank);
         std::lock_guard<std::mutex> lk(job->mu);
+        if (job->abandoned && c) {
+            typedef ncclResult_t (*abort_fn)(ncclComm_t);
+            abort_fn ab = (abort_fn)dlsym(rccl().lib, "ncclCommAbort");
+            if (ab) (void)ab(c); else (void)rccl().CommDestroy(c);
+            c = nullptr;
+        }
         job->comm = c; job->res = r; job->hip_err = he; job->done = true;
         job->cv.notify_all();
     }).detach();
     std::unique_lock<std::mutex> lk(job->mu);
     const bool in_time = limit <= 0 ? (job->cv.wait(lk, [&] { return job->done; }), true)
                                     : job->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->done; });
+    if (!in_time) job->abandoned = true;                     // (under job->mu: the helper sees it before it publishes a communicator)
     if (!in_time) { err = "ncclCommInitRank did not return within " + std::to_string((int)limit) + " s (rank " + std::to_string(rank) + " of " + std::to_string(world) + "; $NIK_GROUP_INIT_TIMEOUT)"; return NIK_ERR_HIP; }
     if (!job->hip_err.empty()) { err = job->hip_err; return NIK_ERR_HIP; }
     if (job->res != ncclSuccess) { err = std::string("ncclCommInitRank: ") + rccl().GetErrorString(job->res); return NIK_ERR_HIP; }

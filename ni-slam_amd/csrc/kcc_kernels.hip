@@ -83,6 +83,17 @@ static int ablate_flags() { return 0; }
 #define ABL(a, bit) false
 #endif
 
+// Upper bounds by deletion (tuning builds only; results become garbage, TIMES stay meaningful): what a remedy could return at
+// most, measured before it is built (round 6).
+//   KCC_UB_NOMOMENTS  the arg-max kernels accumulate no PSR moments   -> ceiling of "moments by Parseval in solve_inv"
+//   KCC_UB_NOZZFWD    solve_inv skips the forward transform of Kzz    -> twice the ceiling of "Kzz real-line pairs" (5 transforms per line pair instead of 6)
+//   KCC_UB_POLAR8     the polar gather reads 8-byte sample entries    -> ceiling of "8-byte polar sample table"
+// (-DKCC_UB_TIMING_ONLY: the same deletion on the RELEASE code generation -- the ablation build's ABL() branches change register
+// allocation, e.g. its polar kernel takes 0.255 ms against the release's 0.226 -- for a variant library that is only ever timed)
+#if !defined(KCC_ABLATE) && !defined(KCC_UB_TIMING_ONLY) && (defined(KCC_UB_NOMOMENTS) || defined(KCC_UB_NOZZFWD) || defined(KCC_UB_POLAR8))
+#error "KCC_UB_* variants produce wrong results: tuning library (-DKCC_ABLATE) only"
+#endif
+
 // lines per A-type workgroup: 16 cf2 = one 128-byte segment per spectrum row; the long polar lines (h = 360)
 // use 8 so that twice as many independent workgroups fit in a CU's LDS (their phases overlap better)
 #ifndef KCC_ALX360
@@ -719,8 +730,14 @@ __global__ __launch_bounds__(FCfg<HH>::NT, ((SRC == SRC_ROT || SRC == SRC_ROT8) 
             }
             uint4 e[QS];
             if (j < D::MF) {
+#ifdef KCC_UB_POLAR8
+                const uint2* pts2 = reinterpret_cast<const uint2*>(a.polar_pts) + (size_t)bx * D::RF * C::NT + tid;
+#pragma unroll
+                for (int qq = 0; qq < QS; ++qq) { const uint2 h2 = pts2[(size_t)(seg * QS + qq) * C::NT]; e[qq] = make_uint4(h2.x, h2.y & 0x7FFFu, h2.x + 2u, (h2.y & 0x7FFFu) + 2u); }
+#else
 #pragma unroll
                 for (int qq = 0; qq < QS; ++qq) e[qq] = pts[(size_t)(seg * QS + qq) * C::NT];
+#endif
             }
             __syncthreads();
             if (j < D::MF && !ABL(a, 32)) {
@@ -1162,7 +1179,9 @@ __global__ __launch_bounds__((ICfg<HH, EPI, LXO>::NT), (ICfg<HH, EPI, LXO>::WPS)
                     if (g0 > best) { best = g0; bidx = li; }
                     if (g1 > best) { best = g1; bidx = li + 1; }
                 }
+#ifndef KCC_UB_NOMOMENTS
                 s1 += g0 + g1; s2 += g0 * g0 + g1 * g1;
+#endif
             }
         }
         double d1 = (double)s1, d2 = (double)s2;
@@ -1677,11 +1696,26 @@ __global__ __launch_bounds__((BCfg<N, MODE>::NT)) void kB(BArgs a) {
             if (C::SEQ) {
                 cf2 (&v0)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[0]); cf2 (&v1)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[1]);
                 cf2 (&k0)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[0]);  cf2 (&k1)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[1]);
+#ifdef KCC_UB_NOZZFWD
+                (void)v0;
+#pragma unroll
+                for (int q = 0; q < DF::RL; ++q) k0[0][q] = vin[0][q % DF::RF];
+                fft_chain<P, false, 1, WLB>(v1, k1, j, ex1, a.tw_f);
+#else
                 fft_chain<P, false, 1, WLB>(v0, k0, j, ex1, a.tw_f);
                 __syncthreads();
                 fft_chain<P, false, 1, WLB>(v1, k1, j, ex1, a.tw_f);
+#endif
             } else {
+#ifdef KCC_UB_NOZZFWD
+                cf2 (&v1)[1][DF::RF] = reinterpret_cast<cf2 (&)[1][DF::RF]>(vin[1]); cf2 (&k1)[1][DF::RL] = reinterpret_cast<cf2 (&)[1][DF::RL]>(kk[1]);
+#pragma unroll
+                for (int q = 0; q < DF::RL; ++q) kk[0][q] = vin[0][q % DF::RF];
+                cf2* const exu[1] = { ex2[1] };
+                fft_chain<P, false, 1>(v1, k1, j, exu, a.tw_f);
+#else
                 fft_chain<P, false, 2>(vin, kk, j, ex2, a.tw_f);
+#endif
             }
         }
         const float rzz = 1.0f / s_rmax[0], rxz = 1.0f / s_rmax[1];   // (wave 0 wrote them before the barriers inside the chains)

@@ -311,7 +311,8 @@ static int optimize(int device, int n_poses, const int32_t* ids, double* poses, 
             step.assign(P.dim, 0.0);
             const int sr = kcc_pg::dev_solve(dev, damp.data(), step.data(), nullptr);
             if (sr < 0) return NIK_ERR_HIP;
-            solved = sr == 0;
+            solved = sr == 0 || sr == 2;                  // 2: iteration limit before tolerance -- tried on its merits, and counted
+            if (sr == 2) sm.inexact_solves += 1;
         } else {
             solved = solve(P, N, damp, step);
         }

@@ -312,8 +312,9 @@ int dev_linearize(DevProblem* p, const double* x, double* cost, double* r, doubl
 }
 
 // (J^T J + diag(damp)) step = -g for the point of the latest FULL linearisation (its blocks are still on the device; cost-only
-// evaluations in between leave them alone).  damp, step: host, dim doubles.  Returns 0, 1 (not positive definite: the caller
-// shrinks the trust region, as after a failed host solve) or a negative hipError_t.
+// evaluations in between leave them alone).  damp, step: host, dim doubles.  Returns 0 (solved), 2 (solved INEXACTLY: the PCG
+// iteration limit came before its tolerance; the step is the best iterate), 1 (not positive definite: the caller shrinks the
+// trust region, as after a failed host solve) or a negative hipError_t.
 // (dev_solve's contract is "negative on a HIP error": PG_TRY returns the positive hipError_t, which optimize() would read as
 // "not positive definite" and answer by shrinking the trust region until NIK_PG_FAILURE -- ADVICE r4)
 #define PG_TRYN(p, expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { (p)->err = std::string(#expr) + ": " + hipGetErrorString(e_); return -(int)e_; } } while (0)
@@ -335,7 +336,7 @@ int dev_solve(DevProblem* p, const double* damp, double* step, int* iterations) 
     if (iterations) *iterations = st[1];
     // st[0]: 0 converged, 1 not positive definite, 2 iteration limit reached without convergence (the step is still the best
     // iterate: the trust-region test of the caller accepts or rejects it on its merits)
-    return st[0] == 1 ? 1 : 0;
+    return st[0] == 1 ? 1 : (st[0] == 2 ? 2 : 0);
 }
 
 int dev_cost_async(DevProblem* p, const double* x, double** d_cost, void** stream) {

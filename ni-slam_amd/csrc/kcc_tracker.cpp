@@ -634,6 +634,11 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
     if ((tk[0] = upload(0)) < 0) return bail(tk[0]);
     if (nw > 1 && (tk[1] = upload(1)) < 0) return bail(tk[1]);
     if ((rc = nik_upload_fence(t->ctx, tk[0]))) return bail(rc);
+    // window 0 is prefetched like the others, so that the marker "the upload ring's buffer 0 has been read" sits right behind
+    // its ComputeIntermedium batch -- not behind the whole of push(0) with its look-ahead pose batches, which stalled the staged
+    // uploads of a pageable source
+    if ((rc = nik_tracker_prefetch_dev(t, count(0), t->d_up[0]))) return bail(rc);
+    if (nw > 3 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
     for (int k = 0; k < nw; ++k) {
         if (k + 1 < nw) {
             // window k+1: its upload was enqueued a whole window ago -- wait for it on the device, start its spectra; window k+2:
@@ -650,9 +655,6 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
             if (!no_order && k + 3 < nw && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
         }
         if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return bail(rc);
-        // (window 0 has no prefetch: its ComputeIntermedium batch is enqueued by the push itself, and with max_batch == 1 no waited
-        // registration stands behind it)
-        if (k == 0 && nw > 3 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
     }
     return nik_upload_wait(t->ctx);
 }

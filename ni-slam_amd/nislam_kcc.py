@@ -833,7 +833,7 @@ class Tracker:
         sm = NikPgSummary()
         k = self._L.nik_tracker_optimizations(self._t, C.addressof(sm))
         return k, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
-                       initial_cost=sm.initial_cost, final_cost=sm.final_cost)
+                       initial_cost=sm.initial_cost, final_cost=sm.final_cost, inexact_solves=sm.inexact_solves)
 
     def keyframes(self):
         slots = np.zeros(self._flow.max_frames, np.int32)
@@ -849,7 +849,7 @@ class NikPgConstraint(C.Structure):
 
 
 class NikPgSummary(C.Structure):
-    _fields_ = [("termination", C.c_int32), ("iterations", C.c_int32), ("successful_steps", C.c_int32),
+    _fields_ = [("termination", C.c_int32), ("iterations", C.c_int32), ("successful_steps", C.c_int32), ("inexact_solves", C.c_int32),
                 ("initial_cost", C.c_double), ("final_cost", C.c_double)]
 
 
@@ -911,7 +911,7 @@ def pose_graph_optimize(ids, poses, constraints, max_iterations=300, device=-1):
     if rc:
         raise NikError(rc, "nik_pose_graph_optimize: unknown pose id / no pose 0 / information not positive definite")
     return out, dict(termination=sm.termination, iterations=sm.iterations, successful_steps=sm.successful_steps,
-                     initial_cost=sm.initial_cost, final_cost=sm.final_cost)
+                     initial_cost=sm.initial_cost, final_cost=sm.final_cost, inexact_solves=sm.inexact_solves)
 
 
 class Stitcher:

@@ -79,6 +79,42 @@ def check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun
     return ok, exact_rot, msg
 
 
+def parity_detail(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=None, tie_rel=None):
+    """check_pose_parity with the LETTER of the result spelled out.  Returns a dict:
+      ok            the rule of check_pose_parity holds
+      kind          "identical" (rotation arg-max row and column equal the oracle's), "mirror_tie" (row differs by PD/2 inside the
+                    measured tie tolerance), "near_tie" (accepted through the imposed re-run) or "fail"
+      theta_equal   the returned theta equals the oracle's value exactly (not merely modulo 2 pi)
+      theta_2pi     theta differs from the oracle's by exactly +-2 pi: the |deg| > 90 -> deg - 180 fold of correlation_flow.cc:108
+                    applied to the mirror row leaves e.g. -355 deg where the oracle's row gives +5 deg
+    A pair whose rotation rows are identical always has theta_equal (same integer row -> same double arithmetic)."""
+    ok, exact_rot, msg = check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol, rerun, tie_rel)
+    if not ok:
+        kind = "fail"
+    elif exact_rot:
+        kind = "identical"
+    elif msg.startswith("near-tie"):
+        kind = "near_tie"
+    else:
+        kind = "mirror_tie"
+    d = gpu["pose"][2] - ora_pose[2]
+    return dict(ok=ok, kind=kind, theta_equal=bool(d == 0.0), theta_2pi=bool(abs(abs(d) - 2 * math.pi) < 1e-9), message=msg)
+
+
+def parity_summary(details):
+    """counts over a list of parity_detail() results: what the bench line's parity_spot_check object and tools/parity_sweep.py report"""
+    n = len(details)
+    return dict(ok=bool(n > 0 and all(d["ok"] for d in details)), pairs=n,
+                rotation_rows_identical=sum(d["kind"] == "identical" for d in details),
+                accepted_mirror_ties=sum(d["kind"] == "mirror_tie" for d in details),
+                accepted_near_ties=sum(d["kind"] == "near_tie" for d in details),
+                failures=sum(d["kind"] == "fail" for d in details),
+                theta_equal_to_oracle=sum(d["theta_equal"] for d in details),
+                theta_differs_by_2pi=sum(d["theta_2pi"] for d in details),
+                note="translation arg-max indices are compared exactly for every pair; theta_differs_by_2pi counts accepted ties whose theta is the oracle's +- 2 pi "
+                     "(the deg - 180 fold of correlation_flow.cc:108 on the mirror row); every pair with identical rotation rows has theta equal to the oracle's exactly")
+
+
 def _compare(gpu, ora_pose, ora_info, psr_rtol):
     msgs = []
     if gpu["pose"][0] != ora_pose[0] or gpu["pose"][1] != ora_pose[1]:

@@ -6,6 +6,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, torch, synth
 from kcc_helpers import check_pose_parity, nik
+import math
 from oracle import kcc_oracle as ko
 N = nik()
 H, W = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (480, 640)
@@ -22,6 +23,8 @@ ora = ko.Oracle(ocfg, H, W)
 out = {"pairs_per_mode": n, "max_theta_deg": max_theta, "kernel": ["polynomial", "gaussian"][kernel], "H": H, "W": W}
 for small in (True, False):
     exact = ties = near = fails = trans_near = 0; worst_psr = 0.0; msgs = []; trans_ties = []; kinds = {}
+    theta_examples = []
+    theta_equal = theta_2pi = theta_2pi_exact_rows = 0        # the LETTER of theta: equal to the oracle's value / off by exactly 2 pi
     for b0 in range(0, n, B):
         m = min(B, n - b0)
         keys, curs, _ = synth.make_batch(m, H, W, seed0=50000 + b0 + (0 if small else 10 ** 6), max_shift=int(os.environ.get("NIK_SWEEP_SHIFT", "48")), max_theta=max_theta)
@@ -45,6 +48,10 @@ for small in (True, False):
                 ora.force_rotation(-1, -1)
                 return r
             ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], 720, rerun=rerun, **({"psr_rtol": 1e-2, "tie_rel": __import__("kcc_helpers").ROT_TIE_REL_GAUSS} if kernel else {}))
+            dth = g["pose"][2] - poses[i][2]
+            theta_equal += bool(dth == 0.0); theta_2pi += bool(abs(abs(dth) - 2 * math.pi) < 1e-9)
+            theta_2pi_exact_rows += bool(ex and dth != 0.0)               # must stay 0: identical rotation rows give identical theta
+            if dth != 0.0 and len(theta_examples) < 6: theta_examples.append(dict(gpu=g["pose"][2], oracle=float(poses[i][2]), gpu_row=g["rot_row"], oracle_row=int(dbgs[i]["rot_row"])))
             near += bool(ok and not ex and msg.startswith("near-tie"))
             exact += bool(ok and ex); ties += bool(ok and not ex and not msg.startswith("near-tie")); fails += (not ok)
             if ok and (ex or not msg.startswith("near-tie")):
@@ -64,5 +71,6 @@ for small in (True, False):
                 kind = "rotation" if "rot argmax" in msg else ("translation" if "translation" in msg else ("psr_only" if "info[" in msg and "theta" not in msg else "other"))
                 kinds[kind] = kinds.get(kind, 0) + 1
             if not ok and len(msgs) < 5: msgs.append("pair %d: %s" % (b0 + i, msg))
-    out["small_rot" if small else "large_rot"] = {"exact": exact, "mirror_tie_accepted": ties, "other_near_tie_verified": near, "translation_near_tie_verified": trans_near, "translation_near_ties(gap,pixels)": trans_ties[:40], "failed": fails, "failed_by_kind": kinds, "worst_psr_rel_err": round(worst_psr, 6), "first_failures": msgs}
+    out["small_rot" if small else "large_rot"] = {"exact": exact, "mirror_tie_accepted": ties, "other_near_tie_verified": near, "translation_near_tie_verified": trans_near, "translation_near_ties(gap,pixels)": trans_ties[:40], "failed": fails, "failed_by_kind": kinds, "worst_psr_rel_err": round(worst_psr, 6), "first_failures": msgs,
+                                                       "theta_equal_to_oracle": theta_equal, "theta_differs_by_2pi": theta_2pi, "theta_differs_with_identical_rotation_rows": theta_2pi_exact_rows, "theta_difference_examples": theta_examples}
 print(json.dumps(out))
