@@ -99,7 +99,7 @@ def _live_rocprof(args, workload, batch):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import rocprof_summary
         out = os.path.join(ROOT, "gpurun_out", "bench_live_prof")
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "40", "--warmup", "10",
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "120", "--warmup", "40",
                "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof", "--repeats", "1"]
         r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=180)
         return r if r["stats"] else None

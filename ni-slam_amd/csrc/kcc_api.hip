@@ -245,7 +245,8 @@ int generic_init(nik_ctx* c) {
 int build_polar_table(nik_ctx* c) {
     const FwdGeom fg = fwd_geom(c->PD / 2);
     PolarPlanHost h; std::string err;
-    if (build_polar_plan(c->H, c->W, c->PD, c->PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err))
+    const char* al = kcc::tune_env("NIK_POLAR_ALIGNED");
+    if (build_polar_plan(c->H, c->W, c->PD, c->PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err, al ? atoi(al) : KCC_POLAR_ALIGNED_DEFAULT))
         return fail(c, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
     uint32_t* d_chunks = nullptr; int* d_first = nullptr; uint4* d_pts = nullptr;
     HIP_TRY(c, hipMalloc(&d_chunks, sizeof(uint32_t) * std::max<size_t>(h.chunks.size(), 1)));
@@ -841,7 +842,7 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     int rc;
     if ((rc = family_init(c, c->img, H, W)) || (rc = family_init(c, c->pol, PD, PC))) return bail(rc);
     c->spec_max = std::max(c->img.spec_elems, c->pol.spec_elems);
-    c->s_elems = (size_t)(W + 1) * (H + 2);
+    c->s_elems = ((size_t)(W + 1) * (H + 2) + 15) / 16 * 16;      // (items 64-byte aligned: the aligned polar staging relies on it)
     c->r_elems = std::max(c->img.real_elems, c->pol.real_elems);
     // the tiled polar gather stages annulus segments of THIS image geometry in LDS: an image size whose segments do not fit
     // sends the polar family to the any-size kernels as well
@@ -1957,7 +1958,8 @@ int nik_host_polar_plan(int H, int W, int PD, int PC, int dims[8], uint32_t** ch
     if (!fft_half_supported(PD / 2)) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "FFT length not instantiated");
     const FwdGeom fg = fwd_geom(PD / 2);
     PolarPlanHost h; std::string err;
-    if (build_polar_plan(H, W, PD, PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err)) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
+    const char* al = kcc::tune_env("NIK_POLAR_ALIGNED");
+    if (build_polar_plan(H, W, PD, PC, fg.lines, fg.threads, fg.rf, fg.mf, fg.lds_bytes, fg.qs_opts, h, err, al ? atoi(al) : KCC_POLAR_ALIGNED_DEFAULT)) return fail(nullptr, NIK_ERR_UNSUPPORTED_SIZE, "%s", err.c_str());
     const int d[8] = { h.qs, h.nseg, h.tiles, h.lines, h.threads, h.rf, h.mf, (int)h.lds_bytes };
     memcpy(dims, d, sizeof(d));
     auto dup = [](const void* src, size_t bytes) { void* p = malloc(std::max<size_t>(bytes, 1)); if (p) memcpy(p, src, bytes); return p; };

@@ -50,7 +50,7 @@ struct Span { uint32_t a, b; int first_chunk; };          // source offsets [a, 
 
 // one (tile, segment): stage list + entries; returns the number of chunks
 int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int seg, int qs, int lines, int threads, int rf, int mf,
-                 std::vector<uint32_t>& chunks, uint32_t* pts /* [rf][lines*threads][4] of this tile */) {
+                 std::vector<uint32_t>& chunks, uint32_t* pts /* [rf][lines*threads][4] of this tile */, int aligned) {
     const int NT = lines * threads;
     std::vector<uint32_t> need;
     need.reserve((size_t)lines * mf * qs * 8);
@@ -76,6 +76,21 @@ int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int
         // nearly straight across neighbouring source columns (top and bottom of the ring) every column would put its taps
         // into the same banks.  Starting the chunks of source column x up to x % 8 pixels early decorrelates them: the
         // simulated bank-conflict cycles of the gather drop from 6.2x to 3.3x the conflict-free count for +19 % chunks.
+        if (aligned) {
+            // ALIGNED form (round 6 experiment): chunks are the 64-byte-aligned pieces of the plane that cover the span, staged
+            // back to back -- a chunk is exactly half a 128-byte line (the item stride is a multiple of 16 floats), a span's
+            // pixels are contiguous in LDS (no shared pixel needed), and neighbouring source columns are decorrelated over the
+            // banks by the plane's own pitch (482 = 2 mod 16: column x + 1 sits two banks further)
+            s.a = (s.a / (uint32_t)aligned) * (uint32_t)aligned;
+            for (uint32_t st = s.a;; st += 16) {
+                chunks.push_back(st);
+                ++nch;
+                if (st + 15 >= s.b) break;
+            }
+            spans.push_back(s);
+            i = k + 1;
+            continue;
+        }
         {
             const uint32_t x = s.a / (uint32_t)SP, y = s.a % (uint32_t)SP;
             s.a -= std::min<uint32_t>(x % 8u, y);
@@ -95,6 +110,7 @@ int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int
         while (hi - lo > 1) { const size_t mid = (lo + hi) / 2; if (spans[mid].a <= off) lo = mid; else hi = mid; }
         const Span& s = spans[lo];
         const uint32_t rel = off - s.a, k = rel / 15;
+        if (aligned) return (uint32_t)s.first_chunk * 16u + rel;
         return (uint32_t)(s.first_chunk + (int)k) * 16u + (rel - 15 * k);
     };
     for (int line = 0; line < lines; ++line)
@@ -114,7 +130,7 @@ int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int
 }  // namespace
 
 int build_polar_plan(int H, int W, int PD, int PC, int lines, int threads, int rf, int mf, size_t fft_lds_bytes, const int qs_opts[3],
-                     PolarPlanHost& out, std::string& err) {
+                     PolarPlanHost& out, std::string& err, int aligned) {
     std::vector<uint32_t> map;
     if (build_polar_map(H, W, PD, PC, map, err)) return -1;
     if (lines <= 0 || PC % lines || rf * mf != PD / 2) { err = "polar tile geometry does not match the plane"; return -1; }
@@ -134,7 +150,7 @@ int build_polar_plan(int H, int W, int PD, int PC, int lines, int threads, int r
         for (int t = 0; t < tiles; ++t)
             for (int s = 0; s < nseg; ++s) {
                 out.seg_first[(size_t)t * nseg + s] = (int)out.chunks.size();
-                const int nch = plan_segment(map, PD, SP, t, s, qs, lines, threads, rf, mf, out.chunks, out.pts.data() + (size_t)t * rf * NT * 4);
+                const int nch = plan_segment(map, PD, SP, t, s, qs, lines, threads, rf, mf, out.chunks, out.pts.data() + (size_t)t * rf * NT * 4, aligned);
                 worst = std::max(worst, nch);
             }
         out.seg_first[(size_t)tiles * nseg] = (int)out.chunks.size();

@@ -20,8 +20,13 @@ struct PolarPlanHost {
     size_t lds_bytes = 0;
 };
 // lines/threads/rf/mf/fft_lds_bytes/qs_opts: kcc_kernels.h fwd_geom(PD/2)
+// aligned = G > 0: a span is staged as back-to-back 16-pixel chunks from its start rounded down to G pixels (16: whole 64-byte
+// pieces of the plane) -- kcc_tables.cpp plan_segment; 0: 16-pixel chunks every 15 pixels, started up to x % 8 pixels early
+#ifndef KCC_POLAR_ALIGNED_DEFAULT
+#define KCC_POLAR_ALIGNED_DEFAULT 16
+#endif
 int build_polar_plan(int H, int W, int PD, int PC, int lines, int threads, int rf, int mf, size_t fft_lds_bytes, const int qs_opts[3],
-                     PolarPlanHost& out, std::string& err);
+                     PolarPlanHost& out, std::string& err, int aligned = KCC_POLAR_ALIGNED_DEFAULT);
 
 // [adelta W | bdelta W | X0 H | Y0 H] of cv::warpAffine for RotateArray(image, degree_arg)
 void rotation_terms(int H, int W, float degree_arg, int* out);

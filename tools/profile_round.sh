@@ -8,8 +8,8 @@ TAG=${1:-rXX}
 WL=${2:-pairs}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out
-B=$([ "$WL" = hd ] && echo 128 || echo 256)
-python $R/tools/rocprof_summary.py $TAG $OUT $B -- python $R/bench.py --workload $WL --steps 40 --warmup 10 --cpu-sample 0 --no-profile --no-cached --no-live-prof
+B=$([ "$WL" = hd ] && echo 128 || echo 512)
+python $R/tools/rocprof_summary.py $TAG $OUT $B -- python $R/bench.py --workload $WL --steps 120 --warmup 40 --cpu-sample 0 --no-profile --no-cached --no-live-prof
 # (gpurun merges gpurun_out/ back, not profiles/: copy gpurun_out/${TAG}_* into profiles/ afterwards)
 cd $R && python bench.py --workload $WL --steps 30 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python -c "
