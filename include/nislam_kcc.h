@@ -427,7 +427,9 @@ int  nik_tracker_guess_gap(const int32_t* gaps, int n);
  * SURVEY 8(d) accounting of that pass), summed over launches.
  * bytes_design = what the launch is BUILT to move: the nominal planes minus what its symmetry shortcuts leave out (the
  * Hermitian half of the Kzz kernel plane; the columns |c| <= Rmax + 1 of the zero-phase image) -- the figure a per-kernel
- * GB/s must be priced on (a kernel priced on bytes it never touches can "exceed" the HBM peak).  bytes_design <= bytes.
+ * GB/s must be priced on (a kernel priced on bytes it never touches can "exceed" the HBM peak) -- plus what it files beside its
+ * transform (the u8 kernel's copy of the image into the frame store).  Measured L2-fill traffic agrees with it within 2 % for
+ * every kernel but two (profiles/r06_design_vs_moved.txt).
  * Enabling resets the accumulators; reading synchronises the stream. */
 typedef struct {
     char    name[64];     /* kernel<length,mode> */

@@ -532,7 +532,8 @@ void enqueue_intermedium(nik_ctx* c, Lane& L, int n, const uint8_t* d_u8, bool d
     } else {
         if (d_u8) {
             const double N = (double)I.real_elems;
-            Stage st(c, L, kname("kA_fwd", c->H / 2, "u8", a_tag(c, I)).c_str(), n * (N + Cb(I)));
+            // (design bytes: the kernel also files the image in the u8 frame store -- N more bytes written, in 16-byte row pieces)
+            Stage st(c, L, kname("kA_fwd", c->H / 2, "u8", a_tag(c, I)).c_str(), n * (N + Cb(I)), n * (2 * N + Cb(I)));
             launch_A_fwd_u8(s, n, c->img.g, c->img.t, d_u8, c->img.real_elems, c->W, c->arena_u8, c->u8_stride, c->u8_pitch, dst, L.tmpA, c->spec_max);
         } else {
             Stage st(c, L, kname("kA_fwd", c->H / 2, "plane", a_tag(c, I)).c_str(), n * (Rb(I) + Cb(I)));

@@ -77,10 +77,15 @@ int plan_segment(const std::vector<uint32_t>& map, int PD, int SP, int tile, int
         // into the same banks.  Starting the chunks of source column x up to x % 8 pixels early decorrelates them: the
         // simulated bank-conflict cycles of the gather drop from 6.2x to 3.3x the conflict-free count for +19 % chunks.
         if (aligned) {
-            // ALIGNED form (round 6 experiment): chunks are the 64-byte-aligned pieces of the plane that cover the span, staged
-            // back to back -- a chunk is exactly half a 128-byte line (the item stride is a multiple of 16 floats), a span's
-            // pixels are contiguous in LDS (no shared pixel needed), and neighbouring source columns are decorrelated over the
-            // banks by the plane's own pitch (482 = 2 mod 16: column x + 1 sits two banks further)
+            // ALIGNED form (round 6, $NIK_POLAR_ALIGNED = G in the tuning library; off by default): the span is staged as back-to-back
+            // 16-pixel chunks from its start rounded down to G pixels.  G = 16 makes every chunk exactly half a 128-byte line (the
+            // item stride is a multiple of 16 floats); neighbouring source columns stay decorrelated over the LDS banks by the
+            // plane's own pitch (482 = 2 mod 16).  Measured (profiles/r06_polar_aligned.txt): in the ABLATION build, whose staging
+            // loop the ABL() branches serialise, G = 16 is 8 % faster (0.257 -> 0.237 ms per 256 items) although it stages 21 % more
+            // chunks in four segments instead of two; G = 1 (contiguous, unaligned, 16 % FEWER chunks) is 10 % slower -- the cost of
+            // the LDS-DMA is lines touched, not bytes.  On the RELEASE code generation, where all DMAs of a segment are in flight
+            // together, the three forms are equal within 0.7 % (0.4468 / 0.4458 / 0.4500 ms per 512 items for G = 16 / 8 / 0):
+            // the staging is hidden there and the old form stays.
             s.a = (s.a / (uint32_t)aligned) * (uint32_t)aligned;
             for (uint32_t st = s.a;; st += 16) {
                 chunks.push_back(st);

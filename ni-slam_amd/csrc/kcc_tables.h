@@ -23,7 +23,7 @@ struct PolarPlanHost {
 // aligned = G > 0: a span is staged as back-to-back 16-pixel chunks from its start rounded down to G pixels (16: whole 64-byte
 // pieces of the plane) -- kcc_tables.cpp plan_segment; 0: 16-pixel chunks every 15 pixels, started up to x % 8 pixels early
 #ifndef KCC_POLAR_ALIGNED_DEFAULT
-#define KCC_POLAR_ALIGNED_DEFAULT 16
+#define KCC_POLAR_ALIGNED_DEFAULT 0
 #endif
 int build_polar_plan(int H, int W, int PD, int PC, int lines, int threads, int rf, int mf, size_t fft_lds_bytes, const int qs_opts[3],
                      PolarPlanHost& out, std::string& err, int aligned = KCC_POLAR_ALIGNED_DEFAULT);
