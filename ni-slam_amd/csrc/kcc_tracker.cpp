@@ -637,8 +637,10 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
     // window 0 is prefetched like the others, so that the marker "the upload ring's buffer 0 has been read" sits right behind
     // its ComputeIntermedium batch -- not behind the whole of push(0) with its look-ahead pose batches, which stalled the staged
     // uploads of a pageable source
+#ifndef KCC_TRK_OLD_MARKER
     if ((rc = nik_tracker_prefetch_dev(t, count(0), t->d_up[0]))) return bail(rc);
     if (nw > 3 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
+#endif
     for (int k = 0; k < nw; ++k) {
         if (k + 1 < nw) {
             // window k+1: its upload was enqueued a whole window ago -- wait for it on the device, start its spectra; window k+2:
@@ -655,6 +657,9 @@ int nik_tracker_push_host(nik_tracker* t, int n, const uint8_t* gray, int stride
             if (!no_order && k + 3 < nw && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
         }
         if ((rc = nik_tracker_push_dev(t, count(k), t->d_up[k % 3], out + (size_t)k * win))) return bail(rc);
+#ifdef KCC_TRK_OLD_MARKER                                 // (round-5 form, kept for the A/B of profiles/r06_push_host_marker.txt)
+        if (k == 0 && nw > 3 && (rc = nik_upload_after_compute(t->ctx))) return bail(rc);
+#endif
     }
     return nik_upload_wait(t->ctx);
 }

@@ -85,8 +85,9 @@ def parity_detail(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=Non
       kind          "identical" (rotation arg-max row and column equal the oracle's), "mirror_tie" (row differs by PD/2 inside the
                     measured tie tolerance), "near_tie" (accepted through the imposed re-run) or "fail"
       theta_equal   the returned theta equals the oracle's value exactly (not merely modulo 2 pi)
-      theta_2pi     theta differs from the oracle's by exactly +-2 pi: the |deg| > 90 -> deg - 180 fold of correlation_flow.cc:108
-                    applied to the mirror row leaves e.g. -355 deg where the oracle's row gives +5 deg
+      theta_2pi     theta differs from the oracle's by +-2 pi (to float precision: theta IS a float in the reference,
+                    correlation_flow.cc:136): the |deg| > 90 -> deg - 180 fold of :108 applied to the mirror row leaves e.g.
+                    -352 deg where the oracle's row gives +8 deg
     A pair whose rotation rows are identical always has theta_equal (same integer row -> same double arithmetic)."""
     ok, exact_rot, msg = check_pose_parity(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol, rerun, tie_rel)
     if not ok:
@@ -98,7 +99,7 @@ def parity_detail(gpu, ora_pose, ora_info, ora_dbg, PD, psr_rtol=2e-3, rerun=Non
     else:
         kind = "mirror_tie"
     d = gpu["pose"][2] - ora_pose[2]
-    return dict(ok=ok, kind=kind, theta_equal=bool(d == 0.0), theta_2pi=bool(abs(abs(d) - 2 * math.pi) < 1e-9), message=msg)
+    return dict(ok=ok, kind=kind, theta_equal=bool(d == 0.0), theta_2pi=bool(abs(abs(d) - 2 * math.pi) < 1e-5), message=msg)
 
 
 def parity_summary(details):

@@ -49,7 +49,7 @@ for small in (True, False):
                 return r
             ok, ex, msg = check_pose_parity(g, poses[i], infos[i], dbgs[i], 720, rerun=rerun, **({"psr_rtol": 1e-2, "tie_rel": __import__("kcc_helpers").ROT_TIE_REL_GAUSS} if kernel else {}))
             dth = g["pose"][2] - poses[i][2]
-            theta_equal += bool(dth == 0.0); theta_2pi += bool(abs(abs(dth) - 2 * math.pi) < 1e-9)
+            theta_equal += bool(dth == 0.0); theta_2pi += bool(abs(abs(dth) - 2 * math.pi) < 1e-5)
             theta_2pi_exact_rows += bool(ex and dth != 0.0)               # must stay 0: identical rotation rows give identical theta
             if dth != 0.0 and len(theta_examples) < 6: theta_examples.append(dict(gpu=g["pose"][2], oracle=float(poses[i][2]), gpu_row=g["rot_row"], oracle_row=int(dbgs[i]["rot_row"])))
             near += bool(ok and not ex and msg.startswith("near-tie"))
