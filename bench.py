@@ -247,6 +247,8 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
     cfg = N.default_config()
     cf = N.CorrelationFlow(cfg, H, W, max_batch=B, max_frames=2 * B, device=local_rank)
     n_streams = cf.set_streams(_streams(args, B, pairs=not hd))
+    if args.chunk > 0:
+        cf.set_chunk(args.chunk)
     key_slots, cur_slots = list(range(B)), list(range(B, 2 * B))
     d_rgb = None
     if hd:
@@ -702,6 +704,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="pairs", choices=["pairs", "sequence", "pyramid", "hd", "loop4096"])
     ap.add_argument("--batch", type=int, default=512, help="frame pairs per GPU per step (pairs workload; round 6: 512 pairs on 2 streams measured +1.5 ... 3 %% over 256 on 3, profiles/r06_batch_sweep.txt)")
+    ap.add_argument("--chunk", type=int, default=0, help="cut every batched call into chunks of at most this many pairs dealt to the streams in turn (nik_set_chunk; 0 = one chunk per stream)")
     ap.add_argument("--streams", type=int, default=0, help="compute streams (lanes) per GPU; 0 = $NIK_STREAMS, else 2 for the pairs workload at >= 384 pairs per step, else the library's 3")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic pairs generated (tiled to --batch); 0 = all of them")
     ap.add_argument("--cpu-sample", type=int, default=256, help="pairs timed on the host for cpu_baseline (0 = skip); 256 pairs ~ 25 core-seconds")
