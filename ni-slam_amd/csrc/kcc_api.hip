@@ -68,6 +68,7 @@ struct Lane {
     float2* tmpA = nullptr;             // [cap_items][max spec]
     float2* kbuf = nullptr;             // [cap_items][2][max spec]  (zz, xz planes)
     float2* gbuf = nullptr;             // [cap_items][max spec]
+    void* slab = nullptr;               // tuning: tmpA | kbuf | gbuf as one allocation ($NIK_LANE_SLAB)
     float*  splane = nullptr;           // [cap_pairs][(W+1)*(H+2)] shifted zero-bordered planes (polar source)
     uint8_t* u8tmp = nullptr;           // [cap_pairs][H*W] undistorted frames (allocated by nik_set_undistort)
     float*  rbuf = nullptr;             // generic-size contexts: [cap_items][2][max real plane] real work planes
@@ -753,9 +754,19 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl, int li) {
     { const int rc = lane_stream_create(c, li, &L.stream); if (rc) return rc; }
     HIP_TRY(c, hipEventCreateWithFlags(&L.write_ev, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&L.tail_ev, hipEventDisableTiming));
+    if (const char* sl = kcc::tune_env("NIK_LANE_SLAB")) {
+        // (round 6 experiment: the three spectrum work buffers of a lane as ONE allocation, pieces `pad` MiB apart beyond their
+        // size -- does the placement lottery of profiles/r06_placement_probe.txt change when their relative offsets are ours?)
+        const size_t unit = sizeof(float2) * c->spec_max * c->max_items, pad = (size_t)std::max(0, atoi(sl)) << 20;
+        const size_t a = (unit + (2u << 20) - 1) / (2u << 20) * (2u << 20) + pad;
+        char* slab = nullptr;
+        HIP_TRY(c, hipMalloc(&slab, 4 * a + pad));
+        L.tmpA = (float2*)slab; L.kbuf = (float2*)(slab + a); L.gbuf = (float2*)(slab + 3 * a + (pad ? pad / 2 : 0)); L.slab = slab;
+    } else {
     HIP_TRY(c, hipMalloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
     HIP_TRY(c, hipMalloc(&L.kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
     HIP_TRY(c, hipMalloc(&L.gbuf, sizeof(float2) * c->spec_max * c->max_items));
+    }
     // (+16: the polar gather stages whole 16-float chunks, the last of which may start at the plane's last pixel)
     HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
     HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * (c->s_elems * c->max_batch + 16)));      // zero borders are never overwritten
@@ -779,7 +790,8 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl, int li) {
 }
 void lane_free(Lane& L) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
-    (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.rbuf); (void)hipFree(L.partials);
+    if (L.slab) (void)hipFree(L.slab); else { (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); }
+    (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.rbuf); (void)hipFree(L.partials);
     (void)hipFree(L.maxbuf); (void)hipFree(L.energy); (void)hipFree(L.rot_res); (void)hipFree(L.trans_res); (void)hipFree(L.d_idx);
     for (Call& call : L.ring) {
         if (call.h_idx) (void)hipHostFree(call.h_idx);
