@@ -728,6 +728,16 @@ inline void chunk_of(int n, int nl, int li, int& b, int& e) {
 // batches of 32 are faster on one stream (pyramid workload 16.3 k -> 19.5 k pairs/s)
 inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->active_lanes, n / c->lane_items)); }
 
+// Big buffers: plain hipMalloc, or -- tuning switch $NIK_CONTIG=1, round 6 -- physically contiguous memory
+// (hipExtMallocWithFlags(hipDeviceMallocContiguous); falls back to hipMalloc when the driver cannot find a contiguous range):
+// the experiment behind profiles/r06_placement_contig.txt (do the run-to-run levels of the HBM-bound kernels come from TLB reach?)
+template <class T> hipError_t big_malloc(T** p, size_t bytes) {
+    static const bool contig = kcc::tune_env("NIK_CONTIG") && atoi(kcc::tune_env("NIK_CONTIG")) != 0;
+    if (contig && hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+    if (contig) (void)hipGetLastError();
+    return hipMalloc((void**)p, bytes);
+}
+
 // Spatial partitions ($NIK_LANE_CUS, round 6): "k0,k1,..." gives lane i a stream whose kernels only run on k_i CUs, laid
 // behind the CUs of the lanes before it; ONE number k gives every lane the first k CUs.  Mask bit b is CU (b / 8) of XCD b % 8
 // (tools/probes/cumask_probe.hip), so any range of bits that starts and ends on a multiple of 8 keeps all eight XCDs with
@@ -763,12 +773,12 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl, int li) {
         HIP_TRY(c, hipMalloc(&slab, 4 * a + pad));
         L.tmpA = (float2*)slab; L.kbuf = (float2*)(slab + a); L.gbuf = (float2*)(slab + 3 * a + (pad ? pad / 2 : 0)); L.slab = slab;
     } else {
-    HIP_TRY(c, hipMalloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
-    HIP_TRY(c, hipMalloc(&L.kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
-    HIP_TRY(c, hipMalloc(&L.gbuf, sizeof(float2) * c->spec_max * c->max_items));
+    HIP_TRY(c, big_malloc(&L.tmpA, sizeof(float2) * c->spec_max * c->max_items));
+    HIP_TRY(c, big_malloc(&L.kbuf, sizeof(float2) * c->spec_max * 2 * c->max_items));
+    HIP_TRY(c, big_malloc(&L.gbuf, sizeof(float2) * c->spec_max * c->max_items));
     }
     // (+16: the polar gather stages whole 16-float chunks, the last of which may start at the plane's last pixel)
-    HIP_TRY(c, hipMalloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
+    HIP_TRY(c, big_malloc(&L.splane, sizeof(float) * (c->s_elems * c->max_batch + 16)));
     HIP_TRY(c, hipMemset(L.splane, 0, sizeof(float) * (c->s_elems * c->max_batch + 16)));      // zero borders are never overwritten
     if (c->generic) HIP_TRY(c, hipMalloc(&L.rbuf, sizeof(float) * 2 * c->r_elems * c->max_items));
     HIP_TRY(c, hipMalloc(&L.partials, sizeof(Partial) * c->partial_stride * c->max_items));
@@ -874,9 +884,9 @@ int nik_create(const nik_config* cfg, int image_height, int image_width, int max
     c->img_stride = (size_t)W * c->img_pitch;
     TRY_C(hipMalloc(&c->arena_img, sizeof(float) * c->img_stride * max_frames));
     c->u8_pitch = W + 16; c->u8_stride = (size_t)c->u8_pitch * H;
-    TRY_C(hipMalloc(&c->arena_u8, c->u8_stride * max_frames));
-    TRY_C(hipMalloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
-    TRY_C(hipMalloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
+    TRY_C(big_malloc(&c->arena_u8, c->u8_stride * max_frames));
+    TRY_C(big_malloc(&c->arena_F, sizeof(float2) * c->img.spec_elems * max_frames));
+    TRY_C(big_malloc(&c->arena_P, sizeof(float2) * c->pol.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_KzF, sizeof(float2) * c->img.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_KzP, sizeof(float2) * c->pol.spec_elems * max_frames));
     TRY_C(hipMalloc(&c->arena_MzF, sizeof(unsigned) * max_frames));
