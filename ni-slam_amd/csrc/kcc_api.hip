@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -731,8 +732,47 @@ inline int lanes_for(const nik_ctx* c, int n) { return std::max(1, std::min(c->a
 // Big buffers: plain hipMalloc, or -- tuning switch $NIK_CONTIG=1, round 6 -- physically contiguous memory
 // (hipExtMallocWithFlags(hipDeviceMallocContiguous); falls back to hipMalloc when the driver cannot find a contiguous range):
 // the experiment behind profiles/r06_placement_contig.txt (do the run-to-run levels of the HBM-bound kernels come from TLB reach?)
+// $NIK_VMM=<MiB> (tuning, round 6): the buffer as a reserved address range backed by separately created physical chunks of that
+// size (hipMemCreate / hipMemMap) -- the probe of profiles/r06_placement_vmm.txt at library scale.
+struct VmmAlloc { size_t size; std::vector<hipMemGenericAllocationHandle_t> handles; };
+static std::map<void*, VmmAlloc>& vmm_registry() { static std::map<void*, VmmAlloc> r; return r; }
+static hipError_t vmm_malloc(void** p, size_t bytes, size_t chunk_mb, int device) {
+    hipMemAllocationProp prop{}; prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    const size_t chunk = std::max(gran, chunk_mb << 20), n = (bytes + chunk - 1) / chunk;
+    void* base = nullptr;
+    if ((e = hipMemAddressReserve(&base, n * chunk, 0, nullptr, 0)) != hipSuccess) return e;
+    VmmAlloc a; a.size = n * chunk;
+    for (size_t k = 0; k < n && e == hipSuccess; ++k) {
+        hipMemGenericAllocationHandle_t h;
+        if ((e = hipMemCreate(&h, chunk, &prop, 0)) != hipSuccess) break;
+        a.handles.push_back(h);
+        e = hipMemMap((char*)base + k * chunk, chunk, 0, h, 0);
+    }
+    hipMemAccessDesc acc{}; acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (e == hipSuccess) e = hipMemSetAccess(base, a.size, &acc, 1);
+    if (e != hipSuccess) { for (auto h : a.handles) (void)hipMemRelease(h); (void)hipMemAddressFree(base, n * chunk); return e; }
+    vmm_registry()[base] = std::move(a);
+    *p = base;
+    return hipSuccess;
+}
+static hipError_t big_free(void* p) {
+    if (!p) return hipSuccess;
+    auto it = vmm_registry().find(p);
+    if (it == vmm_registry().end()) return hipFree(p);
+    (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(p, it->second.size);
+    for (auto h : it->second.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(p, it->second.size);
+    vmm_registry().erase(it);
+    return hipSuccess;
+}
 template <class T> hipError_t big_malloc(T** p, size_t bytes) {
     static const bool contig = kcc::tune_env("NIK_CONTIG") && atoi(kcc::tune_env("NIK_CONTIG")) != 0;
+    static const int vmm = kcc::tune_env("NIK_VMM") ? atoi(kcc::tune_env("NIK_VMM")) : 0;
+    if (vmm > 0) { int dev = 0; (void)hipGetDevice(&dev); return vmm_malloc((void**)p, bytes, (size_t)vmm, dev); }
     if (contig && hipExtMallocWithFlags((void**)p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
     if (contig) (void)hipGetLastError();
     return hipMalloc((void**)p, bytes);
@@ -800,8 +840,8 @@ int lane_alloc(nik_ctx* c, Lane& L, int nl, int li) {
 }
 void lane_free(Lane& L) {
     if (L.stream) (void)hipStreamSynchronize(L.stream);
-    if (L.slab) (void)hipFree(L.slab); else { (void)hipFree(L.tmpA); (void)hipFree(L.kbuf); (void)hipFree(L.gbuf); }
-    (void)hipFree(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.rbuf); (void)hipFree(L.partials);
+    if (L.slab) (void)hipFree(L.slab); else { (void)big_free(L.tmpA); (void)big_free(L.kbuf); (void)big_free(L.gbuf); }
+    (void)big_free(L.splane); (void)hipFree(L.u8tmp); (void)hipFree(L.rbuf); (void)hipFree(L.partials);
     (void)hipFree(L.maxbuf); (void)hipFree(L.energy); (void)hipFree(L.rot_res); (void)hipFree(L.trans_res); (void)hipFree(L.d_idx);
     for (Call& call : L.ring) {
         if (call.h_idx) (void)hipHostFree(call.h_idx);
@@ -926,7 +966,7 @@ void nik_destroy(nik_ctx* c) {
     if (!c) return;
     for (Lane& L : c->lanes) lane_free(L);
     for (Family* f : { &c->img, &c->pol }) for (float2* p : f->d_tw) (void)hipFree(p);
-    (void)hipFree(c->arena_u8); (void)hipFree(c->arena_img); (void)hipFree(c->arena_F); (void)hipFree(c->arena_P);
+    (void)big_free(c->arena_u8); (void)hipFree(c->arena_img); (void)big_free(c->arena_F); (void)big_free(c->arena_P);
     (void)hipFree(c->arena_KzF); (void)hipFree(c->arena_KzP); (void)hipFree(c->arena_MzF); (void)hipFree(c->arena_MzP);
     (void)hipFree(c->ud_map1); (void)hipFree(c->ud_map2); (void)hipFree(c->d_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
