@@ -99,9 +99,18 @@ def _live_rocprof(args, workload, batch):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import rocprof_summary
         out = os.path.join(ROOT, "gpurun_out", "bench_live_prof")
+        # the passes run THIS bench with its HIP-event pass switched on: the rocprofv3 durations and HIP-event durations of ONE
+        # process can then be compared (the method check), next to the main process's own (the HBM-bound kernels sit on
+        # different levels from process to process: profiles/r06_placement_probe.txt)
+        dump = os.path.join(out, "hip_events_in_pass")
+        for f in glob.glob(dump + ".*"):
+            os.remove(f)
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--batch", str(batch), "--steps", "120", "--warmup", "40",
-               "--cpu-sample", "0", "--no-profile", "--no-cached", "--no-live-prof", "--repeats", "1"]
-        r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=180)
+               "--cpu-sample", "0", "--no-cached", "--no-live-prof", "--repeats", "1", "--kernels-dump", dump]
+        r = rocprof_summary.collect(cmd, out, want_pmc=True, timeout=240)
+        dumps = sorted(glob.glob(dump + ".*"), key=os.path.getmtime)
+        if dumps:                                             # (the first pass is the --kernel-trace --stats one)
+            r["hip_events_same_process"] = {k["name"]: k["avg_ms"] for k in json.load(open(dumps[0]))}
         return r if r["stats"] else None
     except Exception as e:                                    # noqa: BLE001
         sys.stderr.write("live rocprof pass failed: %s\n" % str(e)[:300])
@@ -121,8 +130,9 @@ def _roofline(kernels, batch, live=None, contract_bytes_per_unit=None):
     top = kernels[0]
     name = top["name"]
     t_hip = top["avg_ms"]
-    t_roc, roc_src, traffic, tr_src = None, None, None, None
+    t_roc, roc_src, traffic, tr_src, t_hip_same = None, None, None, None, None
     if live is not None:
+        t_hip_same = (live.get("hip_events_same_process") or {}).get(name)
         if name in live["stats"]:
             t_roc, roc_src = live["stats"][name]["avg_ms"], "live rocprofv3 --kernel-trace --stats pass of this run"
         if name in live["traffic"]:
@@ -140,18 +150,29 @@ def _roofline(kernels, batch, live=None, contract_bytes_per_unit=None):
                 traffic, tr_src = pm["traffic_bytes_per_launch"].get(name), "profiles/" + os.path.basename(f) + " (committed, not re-measured)"
     except Exception:                                         # noqa: BLE001
         pass
-    t_use = max(t_hip, t_roc) if t_roc else t_hip
+    t_use = max([t for t in (t_hip, t_roc, t_hip_same) if t])
     ach = top["bytes_per_launch"] / (t_use * 1e-3) / 1e9
     r = dict(bound="hbm", kernel=name, achieved=round(ach, 1), peak=HBM_PEAK / 1e9, unit="GB/s", frac=round(ach / (HBM_PEAK / 1e9), 4),
              traffic=traffic, traffic_source=tr_src, avg_ms=round(t_use, 4), avg_ms_hip_event=t_hip,
              avg_ms_rocprof=None if t_roc is None else round(t_roc, 4), rocprof_source=roc_src,
              bytes_per_launch=top["bytes_per_launch"], share_of_gpu_time=top["share"])
     if t_roc:
+        # Two comparisons.  (1) the METHOD: HIP events against rocprofv3 inside ONE process (the rocprofv3 pass runs this bench with
+        # its HIP-event pass on) -- that is what durations_agree_within_5pct reports when the pass delivered it.  (2) this process
+        # against that one: the HBM-bound kernels sit on discrete levels that change from process to process (up to +- 8 %,
+        # profiles/r06_placement_probe.txt), so this ratio is reported, not asserted.  frac is priced on the LARGEST duration seen.
         r["hip_event_over_rocprof"] = round(t_hip / t_roc, 4)
-        r["durations_agree_within_5pct"] = bool(abs(t_hip / t_roc - 1.0) <= 0.05)
+        if t_hip_same:
+            r["avg_ms_hip_event_in_rocprof_process"] = round(t_hip_same, 4)
+            r["hip_event_over_rocprof_same_process"] = round(t_hip_same / t_roc, 4)
+            r["durations_agree_within_5pct"] = bool(abs(t_hip_same / t_roc - 1.0) <= 0.05)
+            r["durations_compared"] = "HIP events and rocprofv3 --stats of the same process (the live pass); hip_event_over_rocprof compares THIS process with that one"
+        else:
+            r["durations_agree_within_5pct"] = bool(abs(t_hip / t_roc - 1.0) <= 0.05)
+            r["durations_compared"] = "HIP events of this process against rocprofv3 --stats of another run"
         if not r["durations_agree_within_5pct"]:
             sys.stderr.write("WARNING: %s: HIP-event %.4f ms vs rocprof %.4f ms per launch disagree by more than 5 %%; roofline.frac uses the larger\n"
-                             % (name, t_hip, t_roc))
+                             % (name, t_hip_same or t_hip, t_roc))
     if traffic:
         r["frac_moved_bytes"] = round(traffic / (t_use * 1e-3) / HBM_PEAK, 4)
     # the same kernel on the bytes it is built to move (Hermitian-half / trimmed planes taken out of the nominal count)
@@ -369,6 +390,8 @@ def workload_pairs(args, N, torch, dist, np, synth, world, rank, dev, local_rank
         # idle GPU in the numbers and disagreed with rocprofv3 by up to 6 %)
         kernels = [] if args.no_profile else _profile(cf, lambda: cf.track_batch_dev(d_curs.data_ptr(), key_slots, cur_slots, True, sync=False, res=ring[0]),
                                                        max(2, min(args.steps, 20)), n_streams)
+        if args.kernels_dump and kernels:
+            json.dump(kernels, open("%s.%d" % (args.kernels_dump, os.getpid()), "w"))
         # the live rocprofv3 passes run NOW, while the part is as warm as it was under the HIP-event pass above (behind the CPU
         # leg below it would have idled for ~15 s: the HBM-bound dominant kernel then measured up to 7 % off, in either direction)
         live = _live_rocprof(args, "hd" if hd else "pairs", B) if (world == 1 and kernels) else None
@@ -719,6 +742,7 @@ def main():
     ap.add_argument("--min-time", type=float, default=1.0, help="seconds of timed regions to accumulate when --repeats is 0")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event pass")
     ap.add_argument("--no-cached", action="store_true", help="skip the extra Kzz-cached pass (clean rocprof traces)")
+    ap.add_argument("--kernels-dump", default="", help="write the per-kernel HIP-event table to <path>.<pid> (used by the live rocprofv3 passes)")
     ap.add_argument("--no-live-prof", action="store_true", help="skip the live rocprofv3 passes (durations + HBM bytes of the dominant kernel)")
     args = ap.parse_args()
     args.batch_given = any(a == "--batch" or a.startswith("--batch=") for a in sys.argv[1:])
