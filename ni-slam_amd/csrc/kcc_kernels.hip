@@ -1481,10 +1481,16 @@ template <int N, int MODE> struct BCfg {
 #ifndef KCC_B_SEQ_TMAX
 #define KCC_B_SEQ_TMAX 64
 #endif
-    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && T0 < KCC_B_SEQ_TMAX;
+    // KCC_SOLVE_ALT (tuning, round 6): the ridge solve of the long lines (PlanFor's T >= 128: 1280 points) on PlanAlt in the
+    // single-buffer form -- with -DKCC_PA1280=32,40 a two-pass plan of 40 threads per line instead of 20 x 8 x 8 on 160
+#ifndef KCC_SOLVE_ALT
+#define KCC_SOLVE_ALT 0
+#endif
+    static constexpr bool SOLVE_ALT = KCC_SOLVE_ALT && MODE == 4 && T0 >= 128;
+    static constexpr bool SEQ = KCC_B_SEQ_SOLVE && MODE == 4 && (T0 < KCC_B_SEQ_TMAX || SOLVE_ALT);
     static constexpr int NV = (!SEQ && (MODE == 2 || MODE == 3 || MODE == 4)) ? 2 : 1;
     // single-plane modes (not the single-buffer solve, which still holds two planes in registers) use PlanAlt
-    static constexpr bool ALT = !(MODE == 2 || MODE == 3 || MODE == 4);
+    static constexpr bool ALT = !(MODE == 2 || MODE == 3 || MODE == 4) || SOLVE_ALT;
     using P = typename std::conditional<ALT, PlanAlt<N>, PlanFor<N>>::type;
     static constexpr int T = P::T;
     static constexpr int LK = (T >= 128) ? (NV == 2 ? KCC_BLK_HUGE2 : KCC_BLK_HUGE) : (T >= 64 ? (NV == 2 ? KCC_BLK_BIG2 : KCC_BLK_BIG)
